@@ -1,0 +1,73 @@
+"""ctypes binding of libcfd_amd.so (declarations: include/cfd_amd.h).
+
+The library is the ONLY compute path.  If it is missing this module raises at first use --
+there is deliberately no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcfd_amd.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+CONV_K4S2, CONV_K4S1, CONV_K3S1, CONVT_K4S2, DENSE = 0, 1, 2, 3, 4
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("dtype", C.c_int), ("out_dtype", C.c_int),
+                ("B", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("ldx", C.c_int), ("ldy", C.c_int), ("act", C.c_int), ("leaky_slope", C.c_float),
+                ("split_k", C.c_int)]
+
+
+class CfdError(RuntimeError):
+    pass
+
+
+_vp, _i, _f, _d, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
+
+# name -> (restype, argtypes); every symbol include/cfd_amd.h declares
+SIGNATURES = {
+    "cfd_version": (_i, []),
+    "cfd_last_error": (C.c_char_p, []),
+    "cfd_conv_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
+    "cfd_conv_suggest_split_k": (_i, [C.POINTER(ConvDesc)]),
+    "cfd_conv_forward": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cfd_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "cfd_pack_convT_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "cfd_pack_dense_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "cfd_conv_first": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cfd_convT_out": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cfd_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _i, _f, _i, _vp]),
+    "cfd_maxpool2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "cfd_cast_copy": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
+    "cfd_resample_workspace_bytes": (_i64, [_i, _i, _i]),
+    "cfd_resample_nearest": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _d, _d, _d, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and bind every declared symbol (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CfdError(f"{LIB_PATH} is missing: build it with `python -m cfd_amd.build` "
+                       "(the HIP library is the only compute path; there is no fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().cfd_last_error().decode(errors="replace")
+        raise CfdError(f"{what} failed (status {rc}): {msg}")

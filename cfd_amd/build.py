@@ -1,0 +1,68 @@
+"""Build libcfd_amd.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m cfd_amd.build [--force]
+
+The library is built IN-TREE (cfd_amd/lib/libcfd_amd.so) so that it travels with the repo
+snapshot to the GPU box; it is git-ignored.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(OUT_DIR, "libcfd_amd.so")
+ARCH = "gfx950"
+
+# per-file extra flags
+EXTRA = {
+    "resample.hip": ["-ffp-contract=off"],   # bit-exact fp64: no fused multiply-add
+}
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-variable", "-fno-gpu-rdc"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "cfd_amd.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src: str, force: bool) -> str:
+    obj = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+    sp = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), _deps_mtime()):
+        return obj
+    cmd = ["hipcc", *COMMON, *EXTRA.get(src, []), "-c", sp, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, jobs: int = 8) -> str:
+    os.makedirs(OUT_DIR, exist_ok=True)
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        cmd = ["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,66 @@
+// Shared helpers for the gfx950 kernels of libcfd_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/cfd_amd.h"
+
+namespace cfd {
+
+// ---- error reporting ---------------------------------------------------------------
+char *last_error_buf();  // thread-local, 512 bytes (api.hip)
+
+#define CFD_FAIL(code, ...)                                   \
+  do {                                                        \
+    snprintf(cfd::last_error_buf(), 512, __VA_ARGS__);        \
+    return (code);                                            \
+  } while (0)
+
+#define CFD_REQUIRE(cond, ...)                                \
+  do {                                                        \
+    if (!(cond)) CFD_FAIL(CFD_EINVAL, __VA_ARGS__);           \
+  } while (0)
+
+#define CFD_HIP(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) CFD_FAIL(CFD_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+  } while (0)
+
+#define CFD_LAUNCH_CHECK()                                                                        \
+  do {                                                                                            \
+    hipError_t e_ = hipGetLastError();                                                            \
+    if (e_ != hipSuccess) CFD_FAIL(CFD_EHIP, "kernel launch failed: %s", hipGetErrorString(e_));  \
+  } while (0)
+
+// ---- dtypes ------------------------------------------------------------------------
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+static inline size_t dtype_size(int dt) { return dt == CFD_BF16 ? 2 : 4; }
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }  // RNE, NaN-safe (v_cvt_pk_bf16_f32)
+
+// activation in fp32
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case CFD_ACT_LEAKY: return v > 0.f ? v : v * slope;
+    case CFD_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CFD_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace cfd

@@ -1,0 +1,325 @@
+// Direct (non-GEMM) kernels for the first and last layers of the generators / discriminator / CNN,
+// whose channel counts (Cin <= 4 or Cout == 1) do not fill an MFMA tile, and weight re-layout.
+//
+//   cfd_conv_first : e1 (U/models/generator.py:52, P/...:78), c1 incl. the channel concat of
+//                    (src, target) (U/models/discriminator.py:20-23), g1 (DeltaP/models/generator.py:23-24)
+//   cfd_convT_out  : output Conv2DTranspose(1,(4,4),strides 2) + sigmoid (U/models/generator.py:70-71)
+#include "common.h"
+
+namespace cfd {
+
+// ---------------------------------------------------------------------------------------------
+// conv_first: block = one output row segment of TX pixels; the input patch (KS rows x
+// ((TX-1)*S+KS) cols x CIN) is staged in LDS with zero padding (TF 'same': pad 1 before),
+// each thread keeps the weights of its CPT output channels in registers.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int S, int CIN, int CPT, typename TO>
+__global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, const float *__restrict__ x2,
+                                                         int cin1, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, TO *__restrict__ y, int ldy,
+                                                         TO *__restrict__ y2, int ldy2, int Hi, int Wi, int Ho, int Wo,
+                                                         int Cout, int act, int act2, float slope) {
+  constexpr int TX = 32;
+  constexpr int PW = (TX - 1) * S + KS;
+  constexpr int NW = KS * KS * CIN;
+  __shared__ float patch[KS][PW][CIN];
+
+  const int tid = threadIdx.x;
+  const int CG = Cout / CPT;           // channel groups; 256 % CG == 0 checked on the host
+  const int cg = tid % CG;
+  const int slot = tid / CG;
+  const int pstep = 256 / CG;
+
+  const int xtiles = (Wo + TX - 1) / TX;
+  int bid = blockIdx.x;
+  const int xt = bid % xtiles; bid /= xtiles;
+  const int oy = bid % Ho;
+  const int b = bid / Ho;
+  const int ox0 = xt * TX;
+
+  // weights of my channels: wreg[c][tap*CIN + ci]
+  float wreg[CPT][NW];
+  float breg[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const float *wp = w + (size_t)(cg * CPT + c) * NW;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) wreg[c][k] = wp[k];
+    breg[c] = bias ? bias[cg * CPT + c] : 0.f;
+  }
+
+  // stage the patch
+  const int iy0 = oy * S - 1, ix0 = ox0 * S - 1;
+  for (int e = tid; e < KS * PW * CIN; e += 256) {
+    const int ci = e % CIN;
+    const int px = (e / CIN) % PW;
+    const int py = e / (CIN * PW);
+    const int iy = iy0 + py, ix = ix0 + px;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) {
+      const size_t pix = ((size_t)b * Hi + iy) * Wi + ix;
+      v = (ci < cin1) ? x[pix * cin1 + ci] : x2[pix * (CIN - cin1) + (ci - cin1)];
+    }
+    patch[py][px][ci] = v;
+  }
+  __syncthreads();
+
+  for (int px = slot; px < TX; px += pstep) {
+    const int ox = ox0 + px;
+    if (ox >= Wo) break;
+    float accv[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) accv[c] = breg[c];
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          const float v = patch[kh][px * S + kw][ci];
+#pragma unroll
+          for (int c = 0; c < CPT; ++c) accv[c] = fmaf(v, wreg[c][(kh * KS + kw) * CIN + ci], accv[c]);
+        }
+    const size_t opix = ((size_t)b * Ho + oy) * Wo + ox;
+    TO o[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) o[c] = from_f32<TO>(apply_act(accv[c], act, slope));
+    TO *dst = y + opix * ldy + cg * CPT;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) dst[c] = o[c];  // contiguous CPT elements: the compiler merges into one wide store
+    if (y2) {
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) o[c] = from_f32<TO>(apply_act(accv[c], act2, slope));
+      TO *dst2 = y2 + opix * ldy2 + cg * CPT;
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) dst2[c] = o[c];
+    }
+  }
+}
+
+template <int KS, int S, int CIN, int CPT>
+static int launch_conv_first(const float *x, const float *x2, int cin1, const float *w, const float *bias, void *y,
+                             int ldy, void *y2, int ldy2, int B, int Hi, int Wi, int Cout, int act, int act2,
+                             float slope, int out_dtype, hipStream_t st) {
+  const int Ho = Hi / S, Wo = Wi / S;
+  const int CG = Cout / CPT;
+  CFD_REQUIRE(Cout % CPT == 0 && CG <= 256 && 256 % CG == 0, "conv_first: Cout=%d unsupported", Cout);
+  const int blocks = B * Ho * ((Wo + 31) / 32);
+  if (out_dtype == CFD_BF16)
+    hipLaunchKernelGGL((conv_first_kernel<KS, S, CIN, CPT, bf16>), dim3(blocks), dim3(256), 0, st, x, x2, cin1, w, bias,
+                       (bf16 *)y, ldy, (bf16 *)y2, ldy2, Hi, Wi, Ho, Wo, Cout, act, act2, slope);
+  else
+    hipLaunchKernelGGL((conv_first_kernel<KS, S, CIN, CPT, float>), dim3(blocks), dim3(256), 0, st, x, x2, cin1, w,
+                       bias, (float *)y, ldy, (float *)y2, ldy2, Hi, Wi, Ho, Wo, Cout, act, act2, slope);
+  CFD_LAUNCH_CHECK();
+  return CFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// convT_out, step 1: taps[pixel][t] = sum_c x[pixel][c] * W[t][c]   (t = kh*4+kw), on MFMA.
+// One wave owns 16 pixels per iteration; the 16 x Cin weight matrix lives in registers.  Each lane
+// loads 32 contiguous bytes of its pixel per step so a wave-load covers whole 128-B lines; MFMA sums
+// over k in any order, so both operands simply use the same (permuted) k assignment.
+// ---------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void tapgemm_bf16_kernel(const bf16 *__restrict__ x, int ldx,
+                                                          const bf16 *__restrict__ w, float *__restrict__ taps,
+                                                          int npix) {
+  constexpr int STEPS = CIN / 64;  // each step: 64 channels = 2 MFMA k-steps of 32
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 15, fq = lane >> 4;
+  bf16x8 wf[STEPS][2];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) wf[s][h] = *(const bf16x8 *)(w + (size_t)fr * CIN + s * 64 + fq * 16 + h * 8);
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int ntile = (npix + 15) / 16;
+  for (int t = wave_global; t < ntile; t += nwaves) {
+    const int pix = t * 16 + fr;
+    const int pc = pix < npix ? pix : npix - 1;
+    const bf16 *xp = x + (size_t)pc * ldx + fq * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 xa[STEPS][2];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      xa[s][0] = *(const bf16x8 *)(xp + s * 64);
+      xa[s][1] = *(const bf16x8 *)(xp + s * 64 + 8);
+    }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][0], xa[s][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][1], xa[s][1], acc, 0, 0, 0);
+    }
+    if (pix < npix) *(f32x4 *)(taps + (size_t)pix * 16 + fq * 4) = acc;  // rows (taps) fq*4..+3 of column (pixel) fr
+  }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void tapgemm_f32_kernel(const float *__restrict__ x, int ldx,
+                                                         const float *__restrict__ w, float *__restrict__ taps,
+                                                         int npix) {
+  constexpr int STEPS = CIN / 32;  // each step: 32 channels: lane group fq supplies k = 32 s + 8 fq + e
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 wf[STEPS][2];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) wf[s][h] = *(const f32x4 *)(w + (size_t)fr * CIN + s * 32 + fq * 8 + h * 4);
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int ntile = (npix + 15) / 16;
+  for (int t = wave_global; t < ntile; t += nwaves) {
+    const int pix = t * 16 + fr;
+    const int pc = pix < npix ? pix : npix - 1;
+    const float *xp = x + (size_t)pc * ldx + fq * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const f32x4 a0 = *(const f32x4 *)(xp + s * 32);
+      const f32x4 a1 = *(const f32x4 *)(xp + s * 32 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][0][e], a0[e], acc, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][1][e], a1[e], acc, 0, 0, 0);
+    }
+    if (pix < npix) *(f32x4 *)(taps + (size_t)pix * 16 + fq * 4) = acc;
+  }
+}
+
+// step 2: out[b][oy][ox] = bias + sum over the (<=4) (input pixel, tap) pairs with oy = 2*iy + kh - 1
+__global__ void convT_out_gather_kernel(const float *__restrict__ taps, const float *__restrict__ bias,
+                                        float *__restrict__ y, float *__restrict__ logits, int B, int Hi, int Wi,
+                                        int apply_sigmoid) {
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  const int64_t total = (int64_t)B * Ho * Wo;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % Wo);
+    const int oy = (int)((idx / Wo) % Ho);
+    const int b = (int)(idx / ((int64_t)Wo * Ho));
+    float s = bias ? bias[0] : 0.f;
+    // fixed summation order: kh ascending, kw ascending
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int kh = ((oy + 1) & 1) + 2 * a;
+      const int iy = (oy + 1 - kh) >> 1;
+      if ((unsigned)iy >= (unsigned)Hi) continue;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int kw = ((ox + 1) & 1) + 2 * c;
+        const int ix = (ox + 1 - kw) >> 1;
+        if ((unsigned)ix >= (unsigned)Wi) continue;
+        s += taps[(((int64_t)b * Hi + iy) * Wi + ix) * 16 + kh * 4 + kw];
+      }
+    }
+    if (logits) logits[idx] = s;
+    y[idx] = apply_sigmoid ? 1.f / (1.f + expf(-s)) : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight re-layout (Keras -> packed OHWI of the compute dtype)
+// ---------------------------------------------------------------------------------------------
+// src index strides are given explicitly so one kernel serves Conv2D (kh,kw,ci,co), Conv2DTranspose
+// (kh,kw,co,ci) and Dense (ci,co):  packed[co][t][ci] = src[t*st + ci*sci + co*sco]
+template <typename T>
+__global__ void pack_weight_kernel(const float *__restrict__ src, T *__restrict__ dst, int taps, int cin, int cout,
+                                   int64_t st, int64_t sci, int64_t sco) {
+  const int64_t total = (int64_t)taps * cin * cout;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(idx % cin);
+    const int t = (int)((idx / cin) % taps);
+    const int co = (int)(idx / ((int64_t)cin * taps));
+    dst[idx] = from_f32<T>(src[t * st + ci * sci + co * sco]);
+  }
+}
+
+static int pack_weight(const float *src, void *dst, int taps, int cin, int cout, int64_t st, int64_t sci, int64_t sco,
+                       int dtype, void *stream) {
+  CFD_REQUIRE(src && dst, "NULL pointer");
+  CFD_REQUIRE(dtype == CFD_BF16 || dtype == CFD_F32, "bad dtype");
+  const int64_t total = (int64_t)taps * cin * cout;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == CFD_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16 *)dst,
+                       taps, cin, cout, st, sci, sco);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (float *)dst,
+                       taps, cin, cout, st, sci, sco);
+  CFD_LAUNCH_CHECK();
+  return CFD_OK;
+}
+
+}  // namespace cfd
+
+using namespace cfd;
+
+extern "C" int cfd_pack_conv_weight(const float *keras_hwio, void *packed, int kh, int kw, int cin, int cout,
+                                    int dtype, void *stream) {
+  return pack_weight(keras_hwio, packed, kh * kw, cin, cout, (int64_t)cin * cout, cout, 1, dtype, stream);
+}
+extern "C" int cfd_pack_convT_weight(const float *keras_hwoi, void *packed, int kh, int kw, int cin, int cout,
+                                     int dtype, void *stream) {
+  return pack_weight(keras_hwoi, packed, kh * kw, cin, cout, (int64_t)cin * cout, 1, cin, dtype, stream);
+}
+extern "C" int cfd_pack_dense_weight(const float *keras_io, void *packed, int in, int out, int dtype, void *stream) {
+  return pack_weight(keras_io, packed, 1, in, out, 0, out, 1, dtype, stream);
+}
+
+extern "C" int cfd_conv_first(const float *x, const float *x2, int cin1, int cin2, const float *w, const float *bias,
+                              void *y, int ldy, void *y2, int ldy2, int B, int Hi, int Wi, int Cout, int ksize,
+                              int stride, int act, int act2, float slope, int out_dtype, void *stream) {
+  CFD_REQUIRE(x && w && y, "NULL pointer");
+  CFD_REQUIRE(cin2 == 0 || x2, "x2 is NULL but cin2=%d", cin2);
+  CFD_REQUIRE(out_dtype == CFD_BF16 || out_dtype == CFD_F32, "bad out_dtype");
+  CFD_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Hi % stride == 0 && Wi % stride == 0, "bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int cin = cin1 + cin2;
+  if (ksize == 4 && stride == 2 && cin == 1)
+    return launch_conv_first<4, 2, 1, 8>(x, x2, cin1, w, bias, y, ldy, y2, ldy2, B, Hi, Wi, Cout, act, act2, slope,
+                                         out_dtype, st);
+  if (ksize == 4 && stride == 2 && cin == 2)
+    return launch_conv_first<4, 2, 2, 4>(x, x2, cin1, w, bias, y, ldy, y2, ldy2, B, Hi, Wi, Cout, act, act2, slope,
+                                         out_dtype, st);
+  if (ksize == 3 && stride == 1 && cin == 1)
+    return launch_conv_first<3, 1, 1, 8>(x, x2, cin1, w, bias, y, ldy, y2, ldy2, B, Hi, Wi, Cout, act, act2, slope,
+                                         out_dtype, st);
+  CFD_FAIL(CFD_EUNSUPPORTED, "conv_first: k=%d s=%d cin=%d not built", ksize, stride, cin);
+}
+
+extern "C" int cfd_convT_out(const void *x, int ldx, const void *w, const float *bias, float *taps, float *y,
+                             float *logits, int B, int Hi, int Wi, int Cin, int dtype, int apply_sigmoid,
+                             void *stream) {
+  CFD_REQUIRE(x && w && taps && y, "NULL pointer");
+  CFD_REQUIRE(dtype == CFD_BF16 || dtype == CFD_F32, "bad dtype");
+  CFD_REQUIRE(ldx >= Cin && ldx % (dtype == CFD_BF16 ? 8 : 4) == 0, "bad ldx=%d", ldx);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t npix64 = (int64_t)B * Hi * Wi;
+  CFD_REQUIRE(npix64 > 0 && npix64 < (1LL << 31), "bad pixel count");
+  const int npix = (int)npix64;
+  const int ntile = (npix + 15) / 16;
+  int blocks = (ntile + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+#define TAPGEMM(C)                                                                                              \
+  if (Cin == C) {                                                                                               \
+    if (dtype == CFD_BF16)                                                                                      \
+      hipLaunchKernelGGL(tapgemm_bf16_kernel<C>, dim3(blocks), dim3(256), 0, st, (const bf16 *)x, ldx,          \
+                         (const bf16 *)w, taps, npix);                                                          \
+    else                                                                                                        \
+      hipLaunchKernelGGL(tapgemm_f32_kernel<C>, dim3(blocks), dim3(256), 0, st, (const float *)x, ldx,          \
+                         (const float *)w, taps, npix);                                                         \
+  } else
+  TAPGEMM(512) TAPGEMM(256) TAPGEMM(128) TAPGEMM(64) { CFD_FAIL(CFD_EUNSUPPORTED, "convT_out: Cin=%d not built", Cin); }
+#undef TAPGEMM
+  CFD_LAUNCH_CHECK();
+  const int64_t total = (int64_t)B * 4 * Hi * Wi;
+  const int gb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(convT_out_gather_kernel, dim3(gb), dim3(256), 0, st, (const float *)taps, bias, y, logits, B, Hi,
+                     Wi, apply_sigmoid);
+  CFD_LAUNCH_CHECK();
+  return CFD_OK;
+}

@@ -1,0 +1,385 @@
+// Implicit-GEMM convolutions on gfx950 MFMA (bf16 16x16x32 and exact-f32 16x16x4).
+//
+// Replaces the Conv2D / Conv2DTranspose / Dense arithmetic Keras runs for
+//   U/models/generator.py:18,31,59   P/models/generator.py:43,56,85
+//   U/models/discriminator.py:25-41  DeltaP/models/generator.py:28-46
+//
+// GEMM view (per output "class"):   C[n][m] = sum_k  W[n][k] * X[k][m]
+//   n = output channel,  m = (b, qy, qx) position in the class grid,  k = (tap, ci)
+//   conv kinds  : one class, class grid = output grid, tap = (kh,kw), input pixel
+//                 (qy*S - pad + kh, qx*S - pad + kw), zero outside the image (TF 'same')
+//   transposed  : four classes = output parity (ph,pw); class grid = INPUT grid; each class is a
+//                 2x2-tap convolution (sub-pixel decomposition -> no scatter-add, no atomics);
+//                 output pixel (2qy+ph, 2qx+pw);  oh = 2*ih + kh - 1
+//   dense       : 1x1 grid, one tap
+// The weight operand is the MFMA "A" side (rows = n) and the gathered activations the "B" side
+// (cols = m), so that every lane ends up holding 4 CONSECUTIVE channels of one pixel and the
+// NHWC store is 8 B (bf16) / 16 B (f32) per lane.
+//
+// Tile: 128(n) x 128(m) x 128 bytes of K (64 bf16 / 32 f32), 256 threads = 2x2 waves of 64x64,
+// double-buffered LDS (64 KiB) filled by global_load_lds (16 B per lane).  The LDS image is
+// lane-linear (rows of 128 B); bank conflicts are avoided by XOR-swizzling the 16-B chunk index
+// with (row & 7) on the per-lane SOURCE address and on the fragment read.  Out-of-image taps
+// and rows past M/N read a 16-B zero page, so padding costs no branches in the K loop.
+#include "common.h"
+
+namespace cfd {
+
+struct IgemmParams {
+  const char *x;
+  const char *w;
+  const float *bias;
+  char *y;
+  float *ws;
+  int B, Hi, Wi, Cin, Cout, ldx, ldy;
+  int Hq, Wq, M;       // class grid and rows per class
+  int Ho, Wo;          // output grid
+  int Kw;              // weight row length (all taps * Cin)
+  int ntaps;           // taps per class
+  int kind, act, out_bf16;
+  float slope;
+  int mtiles, ntiles, nclass, split_k;
+  int cpt;             // K tiles per tap = Cin / BKE
+  int nblocks;
+};
+
+__device__ __attribute__((aligned(16))) const unsigned int g_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+template <typename T> struct Elem;
+template <> struct Elem<bf16> { static constexpr int EPC = 8; static constexpr int BKE = 64; };
+template <> struct Elem<float> { static constexpr int EPC = 4; static constexpr int BKE = 32; };
+
+constexpr int TILE_BYTES = 128 * 128;      // one operand tile: 128 rows x 128 B
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+
+__device__ __forceinline__ void glds16(const char *gsrc, char *lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                   (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BKE = Elem<T>::BKE;
+  constexpr int ES = sizeof(T);
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- XCD-aware block remap (bijective): blocks that share an XCD get a contiguous id range
+  int bid = blockIdx.x;
+  {
+    const int nwg = p.nblocks, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = bid % p.ntiles; bid /= p.ntiles;
+  const int mt = bid % p.mtiles; bid /= p.mtiles;
+  const int cls = bid % p.nclass;
+  const int sk = bid / p.nclass;
+  const int ph = cls >> 1, pw = cls & 1;
+  const int m0 = mt * 128, n0 = nt * 128;
+
+  const int S = (p.kind == CFD_CONV_K4S2) ? 2 : 1;
+
+  // ---- per-lane staging rows: round i covers tile rows (i*4+wave)*8 + lane/8, chunk slot lane%8
+  const int lrow = lane >> 3;
+  const int chunk = (lane & 7) ^ lrow;  // logical 16-B chunk this lane fetches (swizzle on the source)
+  int ybase[4], xbase[4], pix0[4];
+  bool mval[4];
+  const char *wrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int R = (i * 4 + wave) * 8 + lrow;
+    const int m = m0 + R;
+    mval[i] = m < p.M;
+    const int mm = mval[i] ? m : 0;
+    const int b = mm / (p.Hq * p.Wq);
+    const int rem = mm - b * (p.Hq * p.Wq);
+    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    ybase[i] = qy * S;
+    xbase[i] = qx * S;
+    pix0[i] = (b * p.Hi + qy * S) * p.Wi + qx * S;
+    const int n = n0 + R;
+    wrow[i] = (n < p.Cout) ? p.w + ((int64_t)n * p.Kw + chunk * EPC) * ES : nullptr;
+  }
+  const char *zero = (const char *)g_zero_page;
+
+  const int ktiles = p.ntaps * p.cpt;
+  const int kbeg = (int)((int64_t)ktiles * sk / p.split_k);
+  const int kend = (int)((int64_t)ktiles * (sk + 1) / p.split_k);
+
+  auto stage = [&](int kt, int buf) {
+    const int t = kt / p.cpt;
+    const int ci0 = (kt - t * p.cpt) * BKE;
+    int dy, dx, wtap;
+    if (p.kind == CFD_CONVT_K4S2) {
+      const int kh = (1 - ph) + 2 * (t >> 1), kw = (1 - pw) + 2 * (t & 1);
+      dy = (ph + 1 - kh) / 2;
+      dx = (pw + 1 - kw) / 2;
+      wtap = kh * 4 + kw;
+    } else if (p.kind == CFD_CONV_K3S1) {
+      const int kh = t / 3, kw = t - kh * 3;
+      dy = kh - 1; dx = kw - 1; wtap = t;
+    } else if (p.kind == CFD_DENSE) {
+      dy = 0; dx = 0; wtap = 0;
+    } else {
+      dy = (t >> 2) - 1; dx = (t & 3) - 1; wtap = t;
+    }
+    char *wdst = lds + buf * STAGE_BYTES + wave * 1024;
+    char *xdst = wdst + TILE_BYTES;
+    const int64_t woff = ((int64_t)wtap * p.Cin + ci0) * ES;
+    const int xoff = ci0 + chunk * EPC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char *ws = wrow[i] ? wrow[i] + woff : zero;
+      glds16(ws, wdst + i * 4096);
+      const int iy = ybase[i] + dy, ix = xbase[i] + dx;
+      const bool ok = mval[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const char *xs = ok ? p.x + ((int64_t)(pix0[i] + dy * p.Wi + dx) * p.ldx + xoff) * ES : zero;
+      glds16(xs, xdst + i * 4096);
+    }
+  };
+
+  // ---- accumulators: wave tile 64(n) x 64(m) = 4x4 fragments of 16x16
+  const int wm = wave & 1, wn = wave >> 1;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  // fragment byte offsets inside a tile for k-step 0 (k-step 1 is chunk + 4)
+  int aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wn * 64 + i * 16 + fr;
+    aoff[i] = ra * 128 + ((fq ^ (ra & 7)) << 4);
+    const int rb = wm * 64 + i * 16 + fr;
+    boff[i] = TILE_BYTES + rb * 128 + ((fq ^ (rb & 7)) << 4);
+  }
+
+  if (kbeg < kend) stage(kbeg, 0);
+  for (int kt = kbeg; kt < kend; ++kt) {
+    const int buf = (kt - kbeg) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile kt has landed for every wave; every wave is done reading the other buffer
+    if (kt + 1 < kend) stage(kt + 1, buf ^ 1);
+    const char *base = lds + buf * STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      // chunk index for this k-step is (s*4 + fq); XOR with (row&7) only touches the low 3 bits, and
+      // s*4 flips bit 2 -> equivalent to xor-ing the byte offset with 64
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a[i] = *(const bf16x8 *)(base + (aoff[i] ^ (s << 6)));
+          b[i] = *(const bf16x8 *)(base + (boff[i] ^ (s << 6)));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      } else {
+        // f32: lane group fq supplies k = 16 s + 4 fq + e for e = 0..3 on BOTH operands (any
+        // consistent k assignment sums to the same dot product), so one 16-B read feeds 4 MFMAs
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a[i] = *(const f32x4 *)(base + (aoff[i] ^ (s << 6)));
+          b[i] = *(const f32x4 *)(base + (boff[i] ^ (s << 6)));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds channels n..n+3 (reg index) of pixel m
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + fr;
+    if (m >= p.M) continue;
+    const int b = m / (p.Hq * p.Wq);
+    const int rem = m - b * (p.Hq * p.Wq);
+    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    int64_t opix;
+    if (p.kind == CFD_CONVT_K4S2)
+      opix = ((int64_t)b * p.Ho + 2 * qy + ph) * p.Wo + 2 * qx + pw;
+    else
+      opix = m;  // class grid == output grid
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + i * 16 + fq * 4;
+      if (n >= p.Cout) continue;
+      f32x4 v = acc[i][j];
+      if (p.split_k > 1) {
+        float *dst = p.ws + ((int64_t)sk * p.B * p.Ho * p.Wo + opix) * p.Cout + n;
+        if (n + 3 < p.Cout) {
+          *(f32x4 *)dst = v;
+        } else {
+          for (int r = 0; r < 4 && n + r < p.Cout; ++r) dst[r] = v[r];
+        }
+        continue;
+      }
+      if (n + 3 < p.Cout) {
+        if (p.bias) {
+          const f32x4 bv = *(const f32x4 *)(p.bias + n);
+          v += bv;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.slope);
+        if (p.out_bf16) {
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;
+        } else {
+          *(f32x4 *)(p.y + (opix * p.ldy + n) * 4) = v;
+        }
+      } else {
+        for (int r = 0; r < 4 && n + r < p.Cout; ++r) {
+          float s = v[r] + (p.bias ? p.bias[n + r] : 0.f);
+          s = apply_act(s, p.act, p.slope);
+          if (p.out_bf16)
+            *(bf16 *)(p.y + (opix * p.ldy + n + r) * 2) = (bf16)s;
+          else
+            *(float *)(p.y + (opix * p.ldy + n + r) * 4) = s;
+        }
+      }
+    }
+  }
+}
+
+// sum split-K slabs + bias + activation + convert + strided NHWC store
+__global__ void splitk_epilogue_kernel(const float *ws, const float *bias, char *y, int64_t npix, int Cout, int ldy,
+                                       int split_k, int act, float slope, int out_bf16) {
+  const int64_t total = npix * Cout;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = idx / Cout;
+    const int n = (int)(idx - pix * Cout);
+    float s = 0.f;
+    for (int k = 0; k < split_k; ++k) s += ws[(int64_t)k * total + idx];
+    if (bias) s += bias[n];
+    s = apply_act(s, act, slope);
+    if (out_bf16)
+      *(bf16 *)(y + (pix * ldy + n) * 2) = (bf16)s;
+    else
+      *(float *)(y + (pix * ldy + n) * 4) = s;
+  }
+}
+
+static int fill_params(const cfd_conv_desc *d, IgemmParams &p) {
+  CFD_REQUIRE(d != nullptr, "desc is NULL");
+  CFD_REQUIRE(d->dtype == CFD_BF16 || d->dtype == CFD_F32, "bad dtype %d", d->dtype);
+  CFD_REQUIRE(d->out_dtype == CFD_BF16 || d->out_dtype == CFD_F32, "bad out_dtype %d", d->out_dtype);
+  CFD_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Cin > 0 && d->Cout > 0, "non-positive shape");
+  const int bke = d->dtype == CFD_BF16 ? 64 : 32;
+  CFD_REQUIRE(d->Cin % bke == 0, "Cin=%d must be a multiple of %d for the implicit-GEMM path (use cfd_conv_first)",
+              d->Cin, bke);
+  CFD_REQUIRE(d->ldx >= d->Cin && d->ldy >= d->Cout, "ldx/ldy smaller than the channel count");
+  const int epc = d->dtype == CFD_BF16 ? 8 : 4;
+  CFD_REQUIRE(d->ldx % epc == 0, "ldx=%d must keep 16-B alignment", d->ldx);
+  CFD_REQUIRE(d->ldy % 4 == 0 || d->Cout < 4, "ldy=%d must be a multiple of 4", d->ldy);
+  CFD_REQUIRE(d->split_k >= 1, "split_k must be >= 1");
+  memset(&p, 0, sizeof(p));
+  p.B = d->B; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Cout = d->Cout; p.ldx = d->ldx; p.ldy = d->ldy;
+  p.kind = d->kind; p.act = d->act; p.slope = d->leaky_slope; p.out_bf16 = d->out_dtype == CFD_BF16;
+  p.nclass = 1;
+  switch (d->kind) {
+    case CFD_CONV_K4S2:
+      CFD_REQUIRE(d->Hi % 2 == 0 && d->Wi % 2 == 0, "k4s2 'same' path needs even input (got %dx%d)", d->Hi, d->Wi);
+      p.Ho = d->Hi / 2; p.Wo = d->Wi / 2; p.Hq = p.Ho; p.Wq = p.Wo; p.ntaps = 16; break;
+    case CFD_CONV_K4S1: p.Ho = d->Hi; p.Wo = d->Wi; p.Hq = p.Ho; p.Wq = p.Wo; p.ntaps = 16; break;
+    case CFD_CONV_K3S1: p.Ho = d->Hi; p.Wo = d->Wi; p.Hq = p.Ho; p.Wq = p.Wo; p.ntaps = 9; break;
+    case CFD_CONVT_K4S2:
+      p.Ho = d->Hi * 2; p.Wo = d->Wi * 2; p.Hq = d->Hi; p.Wq = d->Wi; p.ntaps = 4; p.nclass = 4; break;
+    case CFD_DENSE:
+      CFD_REQUIRE(d->Hi == 1 && d->Wi == 1, "dense needs Hi=Wi=1");
+      p.Ho = 1; p.Wo = 1; p.Hq = 1; p.Wq = 1; p.ntaps = 1; break;
+    default: CFD_FAIL(CFD_EINVAL, "unknown conv kind %d", d->kind);
+  }
+  const int alltaps = (d->kind == CFD_CONV_K3S1) ? 9 : (d->kind == CFD_DENSE ? 1 : 16);
+  p.Kw = alltaps * d->Cin;
+  const int64_t M = (int64_t)d->B * p.Hq * p.Wq;
+  CFD_REQUIRE(M < (1LL << 31) && (int64_t)d->B * d->Hi * d->Wi < (1LL << 31), "too many pixels");
+  p.M = (int)M;
+  p.mtiles = cdiv(M, 128);
+  p.ntiles = cdiv(d->Cout, 128);
+  p.cpt = d->Cin / bke;
+  p.split_k = d->split_k;
+  CFD_REQUIRE(p.split_k <= p.ntaps * p.cpt, "split_k=%d exceeds the %d K tiles", p.split_k, p.ntaps * p.cpt);
+  const int64_t nb = (int64_t)p.mtiles * p.ntiles * p.nclass * p.split_k;
+  CFD_REQUIRE(nb < (1LL << 31), "grid too large");
+  p.nblocks = (int)nb;
+  return CFD_OK;
+}
+
+}  // namespace cfd
+
+using namespace cfd;
+
+extern "C" int64_t cfd_conv_workspace_bytes(const cfd_conv_desc *d) {
+  IgemmParams p;
+  if (fill_params(d, p) != CFD_OK) return -1;
+  if (p.split_k <= 1) return 0;
+  return (int64_t)p.split_k * p.B * p.Ho * p.Wo * p.Cout * 4;
+}
+
+extern "C" int cfd_conv_suggest_split_k(const cfd_conv_desc *d) {
+  cfd_conv_desc t = *d;
+  t.split_k = 1;
+  IgemmParams p;
+  if (fill_params(&t, p) != CFD_OK) return 1;
+  const int blocks = p.mtiles * p.ntiles * p.nclass;
+  const int ktiles = p.ntaps * p.cpt;
+  int s = 1;
+  // fill ~2 blocks per CU (512) but keep >= 8 K tiles per slice
+  while (blocks * s * 2 <= 512 && ktiles / (s * 2) >= 8) s *= 2;
+  return s;
+}
+
+extern "C" int cfd_conv_forward(const cfd_conv_desc *d, const void *x, const void *w, const float *bias, void *y,
+                                void *workspace, void *stream) {
+  IgemmParams p;
+  int rc = fill_params(d, p);
+  if (rc != CFD_OK) return rc;
+  CFD_REQUIRE(x && w && y, "NULL tensor pointer");
+  CFD_REQUIRE(p.split_k == 1 || workspace, "split_k=%d needs a workspace", p.split_k);
+  p.x = (const char *)x; p.w = (const char *)w; p.bias = bias; p.y = (char *)y; p.ws = (float *)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t shmem = 2 * STAGE_BYTES;
+  if (d->dtype == CFD_BF16) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      CFD_HIP(hipFuncSetAttribute((const void *)igemm_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(igemm_kernel<bf16>, dim3(p.nblocks), dim3(256), shmem, st, p);
+  } else {
+    static bool attr_done = false;
+    if (!attr_done) {
+      CFD_HIP(hipFuncSetAttribute((const void *)igemm_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(igemm_kernel<float>, dim3(p.nblocks), dim3(256), shmem, st, p);
+  }
+  CFD_LAUNCH_CHECK();
+  if (p.split_k > 1) {
+    const int64_t npix = (int64_t)p.B * p.Ho * p.Wo;
+    const int64_t total = npix * p.Cout;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float *)workspace, bias,
+                       (char *)y, npix, p.Cout, p.ldy, p.split_k, p.act, p.slope, p.out_bf16);
+    CFD_LAUNCH_CHECK();
+  }
+  return CFD_OK;
+}

@@ -1,0 +1,207 @@
+"""GPU parity of each C-ABI op against the CPU oracle (same seeded inputs).
+
+Tolerances (BASELINE.json north_star): max|y - y_ref| / max|y_ref| <= 1e-4 in fp32, <= 2e-2 in bf16.
+The resample is fp64 and must be bit-exact.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as O
+from oracle import resample as OR
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def relerr(y, ref):
+    y, ref = y.double(), ref.double()
+    return float((y - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def q(t, dtype):
+    """round-trip through the compute dtype so the oracle sees the same operand values"""
+    return t.to(dtype).float()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind,B,H,W,cin,cout", [
+    ("k4s2", 2, 8, 16, 64, 128),       # generic encoder conv
+    ("k4s2", 1, 2, 16, 128, 256),      # bottleneck-like: output 1x8, M < tile
+    ("k4s2", 3, 6, 10, 64, 192),       # ragged M and N tiles
+    ("k4s1", 2, 4, 32, 128, 128),      # discriminator c5: asymmetric 'same' padding
+    ("k4s1", 1, 4, 32, 64, 1),         # discriminator c6: one output channel
+    ("k3s1", 2, 8, 16, 64, 128),       # DeltaP convs
+    ("convT", 2, 4, 8, 128, 128),      # decoder
+    ("convT", 1, 1, 8, 64, 256),       # d1: 1x8 input
+    ("dense", 5, 1, 1, 4096, 256),     # fc (split-K)
+    ("dense", 3, 1, 1, 128, 1),        # fc3
+])
+def test_conv_forward(kind, B, H, W, cin, cout, dtype):
+    from cfd_amd import ops
+    dev = "cuda"
+    x = q(rnd((B, H, W, cin), 1), dtype)
+    bias = rnd((cout,), 3, 0.1)
+    if kind == "dense":
+        wk = q(rnd((cin, cout), 2, 0.05), dtype)
+        ref = x.reshape(B, cin) @ wk + bias
+        wp = ops.pack_dense_weight(wk.to(dev), dtype)
+        y = ops.conv_forward(x.reshape(B, cin).to(dev).to(dtype), wp, bias.to(dev), ops.DENSE, cout,
+                             out_dtype=torch.float32)
+    elif kind == "convT":
+        wk = q(rnd((4, 4, cout, cin), 2, 0.05), dtype)
+        ref = O.conv2d_transpose_same(x, wk, bias)
+        wp = ops.pack_convT_weight(wk.to(dev), dtype)
+        y = ops.conv_forward(x.to(dev).to(dtype), wp, bias.to(dev), ops.CONVT_K4S2, cout, out_dtype=torch.float32)
+    else:
+        k, s, code = {"k4s2": (4, 2, ops.CONV_K4S2), "k4s1": (4, 1, ops.CONV_K4S1), "k3s1": (3, 1, ops.CONV_K3S1)}[kind]
+        wk = q(rnd((k, k, cin, cout), 2, 0.05), dtype)
+        ref = O.conv2d_same(x, wk, bias, s)
+        wp = ops.pack_conv_weight(wk.to(dev), dtype)
+        y = ops.conv_forward(x.to(dev).to(dtype), wp, bias.to(dev), code, cout, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    # operands are identical (pre-rounded); only accumulation order differs -> fp32-level agreement in both modes
+    assert relerr(y.cpu(), ref) <= 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_forward_splitk_act_slice(dtype):
+    """split-K path, fused LeakyReLU, bf16/f32 output written into a channel slice of a wider buffer."""
+    from cfd_amd import ops
+    dev = "cuda"
+    B, H, W, cin, cout = 2, 4, 16, 256, 128
+    x = q(rnd((B, H, W, cin), 1), dtype)
+    wk = q(rnd((4, 4, cin, cout), 2, 0.05), dtype)
+    bias = rnd((cout,), 3, 0.1)
+    ref = O.leaky(O.conv2d_same(x, wk, bias, 2))
+    buf = torch.zeros((B, H // 2, W // 2, cout + 64), dtype=dtype, device=dev)
+    ops.conv_forward(x.to(dev).to(dtype), ops.pack_conv_weight(wk.to(dev), dtype), bias.to(dev), ops.CONV_K4S2, cout,
+                     act=ops.ACT_LEAKY, out=buf[..., 64:], split_k=4)
+    torch.cuda.synchronize()
+    assert relerr(buf[..., 64:].float().cpu(), ref) <= TOL[dtype]
+    assert float(buf[..., :64].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,s,c1,c2,cout", [(4, 2, 1, 0, 256), (4, 2, 1, 1, 128), (3, 1, 1, 0, 64)])
+def test_conv_first(k, s, c1, c2, cout, out_dtype):
+    from cfd_amd import ops
+    dev = "cuda"
+    B, H, W = 2, 16, 48
+    x = rnd((B, H, W, c1), 1)
+    x2 = rnd((B, H, W, c2), 4) if c2 else None
+    wk = rnd((k, k, c1 + c2, cout), 2, 0.1)
+    bias = rnd((cout,), 3, 0.1)
+    xin = x if x2 is None else torch.cat([x, x2], -1)
+    pre = O.conv2d_same(xin, wk, bias, s)
+    wp = ops.pack_conv_weight(wk.to(dev), torch.float32)
+    cat = torch.zeros((B, H // s, W // s, cout + 8), dtype=out_dtype, device=dev)
+    y = ops.conv_first(x.to(dev), None if x2 is None else x2.to(dev), wp, bias.to(dev), cout, k, s, ops.ACT_LEAKY,
+                       out_dtype, out2=cat[..., 8:], act2=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    assert relerr(y.float().cpu(), O.leaky(pre)) <= TOL[out_dtype]
+    assert relerr(cat[..., 8:].float().cpu(), torch.relu(pre)) <= TOL[out_dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin", [512, 256])
+def test_convT_out(cin, dtype):
+    from cfd_amd import ops
+    dev = "cuda"
+    B, H, W = 2, 6, 20
+    x = q(rnd((B, H, W, cin), 1), dtype)
+    wk = q(rnd((4, 4, 1, cin), 2, 0.05), dtype)
+    bias = rnd((1,), 3, 0.1)
+    logits_ref = O.conv2d_transpose_same(x, wk, bias)
+    y, logits = ops.convT_out(x.to(dev).to(dtype), ops.pack_convT_weight(wk.to(dev), dtype), bias.to(dev),
+                              want_logits=True)
+    torch.cuda.synchronize()
+    assert relerr(logits.cpu(), logits_ref) <= 1e-4
+    assert relerr(y.cpu(), torch.sigmoid(logits_ref)) <= 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C,drop", [(2, 4, 32, 128, False), (3, 2, 16, 64, True), (1, 16, 128, 32, False)])
+def test_bn_act(B, H, W, C, drop, dtype):
+    from cfd_amd import ops
+    dev = "cuda"
+    x = q(rnd((B, H, W, C), 1) * 0.7 + 0.3, dtype)
+    p = {"l.bn.gamma": 1 + 0.1 * rnd((C,), 2), "l.bn.beta": 0.1 * rnd((C,), 3)}
+    st = {}
+    ref = O.batchnorm(x, p, "l", True, True, st)
+    mask = None
+    if drop:
+        mask = (torch.rand((B, H, W, C), generator=torch.Generator().manual_seed(5)) < 0.5)
+        ref = ref * mask.float() * 2.0
+    mean = torch.empty((B, C), device=dev)
+    var = torch.empty((B, C), device=dev)
+    cat = torch.zeros((B, H, W, 2 * C), dtype=dtype, device=dev)
+    y = ops.bn_act(x.to(dev).to(dtype), p["l.bn.gamma"].to(dev), p["l.bn.beta"].to(dev), ops.ACT_LEAKY,
+                   out2=cat[..., C:], act2=ops.ACT_RELU,
+                   drop_mask=None if mask is None else mask.to(torch.uint8).to(dev), mean=mean, var=var)
+    torch.cuda.synchronize()
+    assert relerr(y.float().cpu(), O.leaky(ref)) <= TOL[dtype]
+    assert relerr(cat[..., C:].float().cpu(), torch.relu(ref)) <= TOL[dtype]
+    assert relerr(mean.cpu(), st["l"][0]) <= 1e-5
+    assert relerr(var.cpu(), st["l"][1]) <= 1e-4
+    # inference-mode BN with given statistics
+    mm, mv = 0.1 * rnd((C,), 7), 1 + 0.1 * rnd((C,), 8).abs()
+    p["l.bn.moving_mean"], p["l.bn.moving_var"] = mm, mv
+    ref2 = O.leaky(O.batchnorm(x, p, "l", False, True))
+    y2 = ops.bn_act(x.to(dev).to(dtype), p["l.bn.gamma"].to(dev), p["l.bn.beta"].to(dev), ops.ACT_LEAKY,
+                    mean=mm.to(dev), var=mv.to(dev), use_moving=True)
+    assert relerr(y2.float().cpu(), ref2) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool2(dtype):
+    from cfd_amd import ops
+    x = q(rnd((2, 8, 12, 64), 1), dtype)
+    ref = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    y = ops.maxpool2(x.cuda().to(dtype))
+    assert torch.equal(y.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "resample_*.npz"))))
+def test_resample_golden_bit_exact(path):
+    """HIP resample vs the outputs of the REAL reference function (tests/golden/make_resample_golden.py)."""
+    from cfd_amd import ops
+    d = np.load(path)
+    h, w = int(d["height"]), int(d["width"])
+    out = ops.resample_nearest([d["points"]], h, w)[0]
+    gold = d["out"]
+    ref, ties = OR.resample(d["points"], h, w, return_ties=True)
+    # bit-exact against the oracle everywhere (same lowest-index tie rule)
+    assert np.array_equal(out.view(np.uint64), ref.view(np.uint64))
+    # bit-exact against the real reference wherever the nearest point is unique
+    neq = (out.view(np.uint64) != gold.view(np.uint64)).any(axis=1)
+    assert not (neq & ~ties).any()
+    if "ties" not in os.path.basename(path):
+        assert not neq.any()
+
+
+def test_resample_batched_ragged():
+    """several cases with different point counts in one launch == one case at a time"""
+    from cfd_amd import ops, synthetic
+    cases = [synthetic.scattered_case(s, n_z=101, n_y=9 + 4 * s, jitter=0.2) for s in range(4)]
+    out = ops.resample_nearest(cases, 32, 128)
+    for c, o in zip(cases, out):
+        assert np.array_equal(o.view(np.uint64), OR.resample(c, 32, 128).view(np.uint64))
+
+
+def test_resample_no_slices_raises():
+    from cfd_amd import ops
+    pts = np.array([[0.0, 0.0, 0.02525, 1.0, 1.0]])  # no point within 1e-4 of any slice
+    with pytest.raises(ValueError):
+        ops.resample_nearest([pts], 8, 16)
