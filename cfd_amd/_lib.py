@@ -41,7 +41,9 @@ SIGNATURES = {
     "cfd_pack_dense_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "cfd_conv_first": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "cfd_convT_out": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "cfd_bn_act": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _i, _f, _i, _vp]),
+    "cfd_bn_act": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, C.c_uint64, _i64, _vp, _i, _vp, _i, _i, _i, _i, _f, _i,
+                        _i, _f, _i, _vp]),
+    "cfd_dropout_mask": (_i, [_vp, _i64, _i, _i, _i, _f, C.c_uint64, _vp]),
     "cfd_maxpool2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cfd_cast_copy": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
     "cfd_resample_workspace_bytes": (_i64, [_i, _i, _i]),

@@ -11,23 +11,78 @@
 
 namespace cfd {
 
+// splitmix64 finaliser over (seed, group index): 8 random bytes, one per element of an aligned group of 8
+__device__ __forceinline__ uint64_t dropout_hash(uint64_t seed, uint64_t group) {
+  uint64_t z = seed + (group + 1) * 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+// the mask the RNG mode of bn_act applies, written out as 0/1 bytes (parity tests feed it to the oracle)
+__global__ void dropout_mask_kernel(uint8_t *__restrict__ out, int64_t total, int64_t e_begin, uint64_t seed,
+                                    unsigned thr) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t e = (uint64_t)(e_begin + idx);
+    const uint64_t h = dropout_hash(seed, e >> 3);
+    out[idx] = (((h >> ((e & 7) * 8)) & 0xff) >= thr) ? 1 : 0;
+  }
+}
+
 template <typename T> struct Vec;
 template <> struct Vec<bf16> { typedef bf16x8 type; static constexpr int N = 8; };
 template <> struct Vec<float> { typedef f32x4 type; static constexpr int N = 4; };
 
-// Block = (sample b, slab of CS channels = 128 bytes per pixel).  TPP threads cover one pixel's slab with
-// 16-B vectors; 256/TPP pixel phases stride over the HW pixels.  Pass 1: shifted sums -> mean, biased var.
-// Pass 2: normalise, dropout, activation(s), store.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_act_kernel(const T *__restrict__ x, int ldx, const float *__restrict__ gamma,
+// vector load/store of VN consecutive elements (16-B pieces)
+template <typename T, int VN> struct VecIO;
+template <> struct VecIO<bf16, 8> {
+  static __device__ __forceinline__ void load(const bf16 *p, float (&f)[8]) {
+    const bf16x8 v = *(const bf16x8 *)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+  }
+  static __device__ __forceinline__ void store(bf16 *p, const float (&f)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
+    *(bf16x8 *)p = v;
+  }
+};
+template <> struct VecIO<float, 8> {
+  static __device__ __forceinline__ void load(const float *p, float (&f)[8]) {
+    const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+  }
+  static __device__ __forceinline__ void store(float *p, const float (&f)[8]) {
+    *(f32x4 *)p = (f32x4){f[0], f[1], f[2], f[3]};
+    *(f32x4 *)(p + 4) = (f32x4){f[4], f[5], f[6], f[7]};
+  }
+};
+template <> struct VecIO<float, 4> {
+  static __device__ __forceinline__ void load(const float *p, float (&f)[4]) {
+    const f32x4 a = *(const f32x4 *)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = a[i];
+  }
+  static __device__ __forceinline__ void store(float *p, const float (&f)[4]) {
+    *(f32x4 *)p = (f32x4){f[0], f[1], f[2], f[3]};
+  }
+};
+
+// Block = (sample b, slab of CS = 8*VN channels).  TPP = 8 threads cover one pixel's slab; 256/TPP pixel
+// phases stride over the HW pixels.  Pass 1: shifted sums -> mean, biased var.  Pass 2: normalise,
+// dropout, activation(s), store.  TI = dtype of the conv output (fp32 or bf16), TO = activation dtype.
+template <typename TI, typename TO, int VN>
+__global__ __launch_bounds__(256) void bn_act_kernel(const TI *__restrict__ x, int ldx, const float *__restrict__ gamma,
                                                     const float *__restrict__ beta, float *__restrict__ mean_io,
                                                     float *__restrict__ var_io, int use_moving,
                                                     const uint8_t *__restrict__ mask, float drop_scale,
-                                                    T *__restrict__ y, int ldy, T *__restrict__ y2, int ldy2, int HW,
+                                                    unsigned drop_thr, uint64_t drop_seed, int64_t sample0,
+                                                    TO *__restrict__ y, int ldy, TO *__restrict__ y2, int ldy2, int HW,
                                                     int C, float eps, int act, int act2, float slope) {
-  typedef typename Vec<T>::type V;
-  constexpr int VN = Vec<T>::N;
-  constexpr int TPP = 8;          // 8 x 16 B = 128 B slab per pixel
+  constexpr int TPP = 8;
   constexpr int CS = TPP * VN;    // channels per slab
   constexpr int PH = 256 / TPP;   // pixel phases
   __shared__ float red[2][PH][CS];
@@ -40,21 +95,20 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T *__restrict__ x, in
   const int cv = (tid % TPP) * VN;  // first channel of my vector inside the slab
   const int ph = tid / TPP;
   const bool cvalid = c0 + cv < C;  // C is a multiple of VN (checked on the host)
-  const T *xb = x + (size_t)b * HW * ldx + c0 + cv;
+  const TI *xb = x + (size_t)b * HW * ldx + c0 + cv;
 
   if (!use_moving) {
     float sh[VN], s1[VN], s2[VN];
 #pragma unroll
     for (int i = 0; i < VN; ++i) { sh[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
     if (cvalid) {
-      const V v0 = *(const V *)xb;  // pixel 0 as the shift: removes the mean from the sums of squares
-#pragma unroll
-      for (int i = 0; i < VN; ++i) sh[i] = to_f32(v0[i]);
+      VecIO<TI, VN>::load(xb, sh);  // pixel 0 as the shift: removes the mean from the sums of squares
       for (int p = ph; p < HW; p += PH) {
-        const V v = *(const V *)(xb + (size_t)p * ldx);
+        float v[VN];
+        VecIO<TI, VN>::load(xb + (size_t)p * ldx, v);
 #pragma unroll
         for (int i = 0; i < VN; ++i) {
-          const float d = to_f32(v[i]) - sh[i];
+          const float d = v[i] - sh[i];
           s1[i] += d;
           s2[i] = fmaf(d, d, s2[i]);
         }
@@ -94,27 +148,34 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T *__restrict__ x, in
   float sc[VN], sf[VN];
 #pragma unroll
   for (int i = 0; i < VN; ++i) { sc[i] = s_scale[cv + i]; sf[i] = s_shift[cv + i]; }
-  T *yb = y + (size_t)b * HW * ldy + c0 + cv;
-  T *y2b = y2 ? y2 + (size_t)b * HW * ldy2 + c0 + cv : nullptr;
+  TO *yb = y + (size_t)b * HW * ldy + c0 + cv;
+  TO *y2b = y2 ? y2 + (size_t)b * HW * ldy2 + c0 + cv : nullptr;
   const uint8_t *mb = mask ? mask + (size_t)b * HW * C + c0 + cv : nullptr;
   for (int p = ph; p < HW; p += PH) {
-    const V v = *(const V *)(xb + (size_t)p * ldx);
     float f[VN];
+    VecIO<TI, VN>::load(xb + (size_t)p * ldx, f);
 #pragma unroll
-    for (int i = 0; i < VN; ++i) f[i] = fmaf(to_f32(v[i]), sc[i], sf[i]);
+    for (int i = 0; i < VN; ++i) f[i] = fmaf(f[i], sc[i], sf[i]);
     if (mb) {
       const uint8_t *mp = mb + (size_t)p * C;
 #pragma unroll
       for (int i = 0; i < VN; ++i) f[i] = mp[i] ? f[i] * drop_scale : 0.f;
-    }
-    V o;
+    } else if (drop_thr) {
+      // counter-based RNG: element e = ((sample0+b)*HW + p)*C + c draws byte (e & 7) of hash(seed, e >> 3)
+      const uint64_t e0 = ((uint64_t)(sample0 + b) * HW + p) * C + c0 + cv;
+      const uint64_t h = dropout_hash(drop_seed, e0 >> 3);
+      const int sh0 = (int)(e0 & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < VN; ++i) o[i] = from_f32<T>(apply_act(f[i], act, slope));
-    *(V *)(yb + (size_t)p * ldy) = o;
+      for (int i = 0; i < VN; ++i) f[i] = (((h >> (sh0 + 8 * i)) & 0xff) >= drop_thr) ? f[i] * drop_scale : 0.f;
+    }
+    float o[VN];
+#pragma unroll
+    for (int i = 0; i < VN; ++i) o[i] = apply_act(f[i], act, slope);
+    VecIO<TO, VN>::store(yb + (size_t)p * ldy, o);
     if (y2b) {
 #pragma unroll
-      for (int i = 0; i < VN; ++i) o[i] = from_f32<T>(apply_act(f[i], act2, slope));
-      *(V *)(y2b + (size_t)p * ldy2) = o;
+      for (int i = 0; i < VN; ++i) o[i] = apply_act(f[i], act2, slope);
+      VecIO<TO, VN>::store(y2b + (size_t)p * ldy2, o);
     }
   }
 }
@@ -161,12 +222,31 @@ __global__ void cast_copy_kernel(const TI *__restrict__ x, int ldx, TO *__restri
 
 using namespace cfd;
 
-extern "C" int cfd_bn_act(const void *x, int ldx, const float *gamma, const float *beta, float *mean, float *var,
-                          int use_moving, const uint8_t *drop_mask, float drop_scale, void *y, int ldy, void *y2,
-                          int ldy2, int B, int HW, int C, float eps, int act, int act2, float slope, int dtype,
-                          void *stream) {
+static inline unsigned drop_threshold(float rate) { return (unsigned)(rate * 256.f + 0.5f); }
+
+extern "C" int cfd_dropout_mask(uint8_t *mask, int64_t sample0, int B, int HW, int C, float rate, uint64_t seed,
+                                void *stream) {
+  CFD_REQUIRE(mask && B > 0 && HW > 0 && C > 0 && C % 8 == 0, "bad arguments");
+  CFD_REQUIRE(rate > 0.f && rate < 1.f, "rate must be in (0,1)");
+  const int64_t total = (int64_t)B * HW * C;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, total,
+                     sample0 * HW * C, seed, drop_threshold(rate));
+  CFD_LAUNCH_CHECK();
+  return CFD_OK;
+}
+
+extern "C" int cfd_bn_act(const void *x, int ldx, int x_dtype, const float *gamma, const float *beta, float *mean,
+                          float *var, int use_moving, const uint8_t *drop_mask, float drop_rate, uint64_t drop_seed,
+                          int64_t sample0, void *y, int ldy, void *y2, int ldy2, int B, int HW, int C, float eps,
+                          int act, int act2, float slope, int dtype, void *stream) {
+  CFD_REQUIRE(drop_rate >= 0.f && drop_rate < 1.f, "drop_rate must be in [0,1)");
+  const float drop_scale = 1.f / (1.f - drop_rate);
+  const unsigned drop_thr = (drop_mask || drop_rate == 0.f) ? 0u : drop_threshold(drop_rate);
+  CFD_REQUIRE(!drop_thr || C % 8 == 0, "RNG dropout needs C %% 8 == 0");
   CFD_REQUIRE(x && gamma && beta && y, "NULL pointer");
   CFD_REQUIRE(dtype == CFD_BF16 || dtype == CFD_F32, "bad dtype");
+  CFD_REQUIRE(x_dtype == CFD_F32 || (x_dtype == CFD_BF16 && dtype == CFD_BF16), "bad x_dtype/dtype combination");
   CFD_REQUIRE(!use_moving || (mean && var), "use_moving needs mean and var");
   const int vn = dtype == CFD_BF16 ? 8 : 4;
   CFD_REQUIRE(C % vn == 0 && ldx % vn == 0 && ldy % vn == 0 && (!y2 || ldy2 % vn == 0),
@@ -175,14 +255,14 @@ extern "C" int cfd_bn_act(const void *x, int ldx, const float *gamma, const floa
   const int cs = 8 * vn;
   const int blocks = B * ((C + cs - 1) / cs);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CFD_BF16)
-    hipLaunchKernelGGL(bn_act_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16 *)x, ldx, gamma, beta, mean,
-                       var, use_moving, drop_mask, drop_scale, (bf16 *)y, ldy, (bf16 *)y2, ldy2, HW, C, eps, act, act2,
-                       slope);
-  else
-    hipLaunchKernelGGL(bn_act_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)x, ldx, gamma, beta, mean,
-                       var, use_moving, drop_mask, drop_scale, (float *)y, ldy, (float *)y2, ldy2, HW, C, eps, act,
-                       act2, slope);
+#define BN_LAUNCH(TI, TO, VN)                                                                                        \
+  hipLaunchKernelGGL((bn_act_kernel<TI, TO, VN>), dim3(blocks), dim3(256), 0, st, (const TI *)x, ldx, gamma, beta,   \
+                     mean, var, use_moving, drop_mask, drop_scale, drop_thr, drop_seed, sample0, (TO *)y, ldy,       \
+                     (TO *)y2, ldy2, HW, C, eps, act, act2, slope)
+  if (dtype == CFD_BF16 && x_dtype == CFD_BF16) BN_LAUNCH(bf16, bf16, 8);
+  else if (dtype == CFD_BF16) BN_LAUNCH(float, bf16, 8);
+  else BN_LAUNCH(float, float, 4);
+#undef BN_LAUNCH
   CFD_LAUNCH_CHECK();
   return CFD_OK;
 }

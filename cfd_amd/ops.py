@@ -164,7 +164,8 @@ def convT_out(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], ap
 
 def bn_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int, out: Optional[torch.Tensor] = None,
            out2: Optional[torch.Tensor] = None, act2: int = ACT_RELU, drop_mask: Optional[torch.Tensor] = None,
-           drop_scale: float = 2.0, mean: Optional[torch.Tensor] = None, var: Optional[torch.Tensor] = None,
+           drop_rate: float = 0.0, drop_seed: int = 0, sample0: int = 0,
+           mean: Optional[torch.Tensor] = None, var: Optional[torch.Tensor] = None,
            use_moving: bool = False, eps: float = 1e-3, slope: float = LEAKY_SLOPE) -> torch.Tensor:
     """BatchNorm (per-sample batch statistics, or given moving statistics) + dropout + activation."""
     B, H, W, Cc = x.shape
@@ -173,12 +174,24 @@ def bn_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int, o
         out = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device)
     yp, ldy = _nhwc(out)
     y2p, ldy2 = (None, 0) if out2 is None else _nhwc(out2)
+    if out2 is not None and out2.dtype != out.dtype:
+        raise _lib.CfdError("out and out2 must share a dtype")
     if drop_mask is not None and (drop_mask.dtype != torch.uint8 or not drop_mask.is_contiguous()):
         raise _lib.CfdError("drop_mask must be dense uint8 NHWC")
-    check(_lib.load().cfd_bn_act(xp, ldx, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), int(use_moving),
-                                 _ptr(drop_mask), drop_scale, yp, ldy, y2p, ldy2, B, H * W, Cc, eps, act, act2, slope,
-                                 _DT[x.dtype], _stream()), "cfd_bn_act")
+    if drop_mask is not None and drop_rate == 0.0:
+        drop_rate = 0.5
+    check(_lib.load().cfd_bn_act(xp, ldx, _DT[x.dtype], _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var),
+                                 int(use_moving), _ptr(drop_mask), drop_rate, drop_seed, sample0, yp, ldy, y2p, ldy2,
+                                 B, H * W, Cc, eps, act, act2, slope, _DT[out.dtype], _stream()), "cfd_bn_act")
     return out
+
+
+def dropout_mask(shape, rate: float, seed: int, sample0: int = 0, device="cuda") -> torch.Tensor:
+    """The uint8 keep-mask bn_act's RNG mode applies for (seed, sample0) on a [B,H,W,C] tensor."""
+    B, H, W, Cc = shape
+    m = torch.empty(shape, dtype=torch.uint8, device=device)
+    check(_lib.load().cfd_dropout_mask(_ptr(m), sample0, B, H * W, Cc, rate, seed, _stream()), "cfd_dropout_mask")
+    return m
 
 
 def maxpool2(x: torch.Tensor) -> torch.Tensor:

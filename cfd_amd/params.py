@@ -1,0 +1,134 @@
+"""Parameter storage for the surrogate nets: one flat fp32 master buffer in KERNEL layouts
+(conv weights packed [Cout][kh][kw][Cin], dense [out][in]) plus a flat shadow copy in the compute
+dtype for the MFMA operands.  Keras layouts appear only at the interchange boundary
+(`load_keras` / `to_keras`, used by checkpoints, get/set_weights and the parity tests).
+
+Order inside the flat buffer: trainable non-BN tensors, then BN gamma/beta (one contiguous range,
+because `define_gan` leaves exactly those of D trainable, U/models/generator.py:79-81), then the
+non-trainable moving statistics.  Every tensor starts on a 64-element boundary so that 16-B vector
+loads (bias, gamma) and a single fused Adam launch over the trainable prefix stay aligned.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+ALIGN = 64
+
+
+class Spec:
+    __slots__ = ("name", "kind", "keras_shape", "packed_shape", "offset", "numel")
+
+    def __init__(self, name: str, kind: str, keras_shape: Tuple[int, ...]):
+        self.name, self.kind, self.keras_shape = name, kind, tuple(keras_shape)
+        if kind == "conv":       # Keras (kh,kw,Cin,Cout) -> [Cout][kh][kw][Cin]
+            kh, kw, ci, co = keras_shape
+            self.packed_shape = (co, kh, kw, ci)
+        elif kind == "convT":    # Keras (kh,kw,Cout,Cin) -> [Cout][kh][kw][Cin]
+            kh, kw, co, ci = keras_shape
+            self.packed_shape = (co, kh, kw, ci)
+        elif kind == "dense":    # Keras (in,out) -> [out][in]
+            ci, co = keras_shape
+            self.packed_shape = (co, ci)
+        else:                    # vec / bn / stat
+            self.packed_shape = tuple(keras_shape)
+        self.numel = int(np.prod(self.packed_shape))
+        self.offset = -1
+
+
+def _group(kind: str, name: str) -> int:
+    if kind == "stat":
+        return 2
+    if kind == "bn":
+        return 1
+    return 0
+
+
+class ParamStore:
+    def __init__(self, specs: List[Spec], device, compute_dtype: torch.dtype):
+        self.device, self.compute_dtype = torch.device(device), compute_dtype
+        ordered = sorted(range(len(specs)), key=lambda i: (_group(specs[i].kind, specs[i].name), i))
+        self.specs: "OrderedDict[str, Spec]" = OrderedDict()
+        off = 0
+        bounds = [0, 0, 0]
+        for i in ordered:
+            s = specs[i]
+            s.offset = off
+            off += (s.numel + ALIGN - 1) // ALIGN * ALIGN
+            self.specs[s.name] = s
+            bounds[_group(s.kind, s.name)] = off
+        self.n_main = bounds[0]                       # [0, n_main): conv/dense kernels + biases
+        self.n_trainable = max(bounds[0], bounds[1])  # [n_main, n_trainable): BN gamma/beta
+        self.n_total = off
+        self.master = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.compute = self.master if compute_dtype == torch.float32 else \
+            torch.zeros(self.n_trainable, dtype=compute_dtype, device=self.device)
+
+    # ---- views -------------------------------------------------------------------------
+    def m(self, name: str) -> torch.Tensor:
+        s = self.specs[name]
+        return self.master[s.offset:s.offset + s.numel].view(s.packed_shape)
+
+    def c(self, name: str) -> torch.Tensor:
+        s = self.specs[name]
+        return self.compute[s.offset:s.offset + s.numel].view(s.packed_shape)
+
+    def refresh_compute(self) -> None:
+        """compute copy <- master (after loading weights; the fused Adam kernel keeps it in sync later)"""
+        if self.compute is not self.master:
+            n = self.n_trainable
+            ops.cast_copy(self.master[:n].view(1, 1, 1, n), self.compute.view(1, 1, 1, n))
+
+    # ---- Keras interchange ----------------------------------------------------------------
+    def load_keras(self, weights: Dict[str, np.ndarray]) -> None:
+        missing = set(self.specs) - set(weights)
+        if missing:
+            raise KeyError(f"missing weights: {sorted(missing)[:5]} ...")
+        for name, s in self.specs.items():
+            w = np.ascontiguousarray(np.asarray(weights[name], dtype=np.float32))
+            if tuple(w.shape) != s.keras_shape:
+                raise ValueError(f"{name}: expected Keras shape {s.keras_shape}, got {w.shape}")
+            src = torch.from_numpy(w).to(self.device)
+            if s.kind == "conv":
+                self.m(name).copy_(ops.pack_conv_weight(src, torch.float32))
+            elif s.kind == "convT":
+                self.m(name).copy_(ops.pack_convT_weight(src, torch.float32))
+            elif s.kind == "dense":
+                self.m(name).copy_(ops.pack_dense_weight(src, torch.float32))
+            else:
+                self.m(name).copy_(src)
+        self.refresh_compute()
+
+    def to_keras(self) -> Dict[str, np.ndarray]:
+        """host-side (checkpoint / test) export in Keras layouts"""
+        out = {}
+        flat = self.master.cpu().numpy()
+        for name, s in self.specs.items():
+            a = flat[s.offset:s.offset + s.numel].reshape(s.packed_shape)
+            if s.kind == "conv":       # [co][kh][kw][ci] -> (kh,kw,ci,co)
+                a = a.transpose(1, 2, 3, 0)
+            elif s.kind == "convT":    # [co][kh][kw][ci] -> (kh,kw,co,ci)
+                a = a.transpose(1, 2, 0, 3)
+            elif s.kind == "dense":
+                a = a.transpose(1, 0)
+            out[name] = np.ascontiguousarray(a)
+        return out
+
+    def init_random_normal(self, seed: int, stddev: float = 0.02) -> None:
+        """RandomNormal(stddev=0.02) kernels, zero biases, BN gamma=1 beta=0, moving mean 0 var 1
+        (U/models/generator.py:16).  Initialisation only -- drawn on the host, uploaded once."""
+        g = torch.Generator().manual_seed(seed)
+        for name, s in self.specs.items():
+            v = self.m(name)
+            if s.kind in ("conv", "convT", "dense"):
+                v.copy_((torch.randn(s.packed_shape, generator=g) * stddev).to(self.device))
+            elif name.endswith("gamma") or name.endswith("moving_var"):
+                v.fill_(1.0)
+            else:
+                v.zero_()
+        self.refresh_compute()

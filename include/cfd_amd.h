@@ -105,16 +105,22 @@ int cfd_convT_out(const void *x, int ldx, const void *w, const float *bias, floa
 /* BatchNormalization(training) + activation, statistics per sample over (H,W)
  * (generator.py:21-23 encoder: BN -> LeakyReLU; generator.py:33-40 decoder:
  * BN -> Dropout -> Concatenate -> ReLU; discriminator.py:26-27).
- *   x        `dtype` [B][HW][C] stride ldx (conv output incl. bias)
+ *   x        `x_dtype` [B][HW][C] stride ldx (conv output incl. bias); fp32 x with bf16 y is allowed
  *   gamma,beta fp32 [C];  eps = 1e-3
  *   use_moving != 0: normalise with mean/var given in `mean`,`var` fp32 [C] (inference-mode BN,
  *                    D inside gan.test_on_batch); otherwise batch statistics are computed and
  *                    written to mean/var fp32 [B][C] (may be NULL)
- *   drop_mask uint8 [B][HW][C] or NULL; kept values scaled by drop_scale
+ *   dropout (Dropout(0.5)(g, training=True), generator.py:36): drop_rate == 0 -> none;
+ *            drop_mask != NULL -> explicit uint8 [B][HW][C] keep-mask; otherwise a counter-based RNG
+ *            keyed by (drop_seed, global element index with the batch starting at sample `sample0`),
+ *            so the draw is independent of batch split / world size.  Kept values * 1/(1-rate).
  *   y        `dtype` stride ldy, through `act`;  y2 (may be NULL) the same through act2 */
-int cfd_bn_act(const void *x, int ldx, const float *gamma, const float *beta, float *mean, float *var,
-               int use_moving, const uint8_t *drop_mask, float drop_scale, void *y, int ldy, void *y2, int ldy2,
-               int B, int HW, int C, float eps, int act, int act2, float leaky_slope, int dtype, void *stream);
+int cfd_bn_act(const void *x, int ldx, int x_dtype, const float *gamma, const float *beta, float *mean, float *var,
+               int use_moving, const uint8_t *drop_mask, float drop_rate, uint64_t drop_seed, int64_t sample0,
+               void *y, int ldy, void *y2, int ldy2, int B, int HW, int C, float eps, int act, int act2,
+               float leaky_slope, int dtype, void *stream);
+/* the keep-mask (0/1 bytes, [B][HW][C]) that cfd_bn_act's RNG mode applies for the same arguments */
+int cfd_dropout_mask(uint8_t *mask, int64_t sample0, int B, int HW, int C, float rate, uint64_t seed, void *stream);
 
 /* MaxPooling2D(2,2) (DeltaP generator.py:26,32,35).  x,y `dtype` NHWC dense. */
 int cfd_maxpool2(const void *x, void *y, int B, int Hi, int Wi, int C, int dtype, void *stream);

@@ -1,0 +1,123 @@
+"""GPU parity of the full graphs against the PyTorch-CPU oracle on identical weights, inputs and
+dropout masks.  Tolerance (north_star): max|y-y_ref|/max|y_ref| <= 1e-4 fp32, <= 2e-2 bf16."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as O
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+
+
+def relerr(y, ref):
+    y, ref = torch.as_tensor(y).double(), torch.as_tensor(ref).double()
+    return float((y - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def rel_l2(y, ref):
+    y, ref = torch.as_tensor(y).double(), torch.as_tensor(ref).double()
+    return float((y - ref).norm() / ref.norm().clamp_min(1e-30))
+
+
+def inputs(B, shape=(64, 512, 1), seed0=0):
+    from cfd_amd import synthetic
+    x, u, p = synthetic.model_batch(range(seed0, seed0 + B), shape[0], shape[1])
+    return x, u, p
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("arch,B,shape", [("U", 2, (64, 512, 1)), ("P", 3, (64, 512, 1)), ("P", 1, (128, 1024, 1))])
+def test_generator_forward(arch, B, shape, dtype):
+    from cfd_amd import nets
+    po = O.init_generator(arch, seed=10, jitter=True)
+    g = nets.Generator(arch, shape, dtype=dtype)
+    g.params.load_keras(O.to_numpy(po))
+    x, _, _ = inputs(B, shape)
+    gen = torch.Generator().manual_seed(3)
+    masks = [(torch.rand(s, generator=gen) < 0.5) for s in O.generator_dropout_shapes(arch, B, shape)]
+    with torch.no_grad():
+        ref = O.generator_forward(po, x, arch, [m.float() for m in masks])
+    y = g.forward(torch.from_numpy(x).cuda(), masks=[m.to(torch.uint8).cuda() for m in masks])
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    e, l2 = relerr(y.cpu(), ref), rel_l2(y.cpu(), ref)
+    print(f"generator {arch} {dtype} B={B} {shape}: rel max err {e:.3e} rel L2 {l2:.3e}")
+    assert e <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_generator_batch_equals_single(dtype):
+    """a batch of B equals B batch-1 predictions (per-sample BN statistics, batch-independent dropout
+    draw); only the split-K factor, hence the fp32 summation order, may differ with the batch size"""
+    from cfd_amd import nets
+    g = nets.Generator("P", dtype=dtype, seed=4)
+    x, _, _ = inputs(3)
+    xd = torch.from_numpy(x).cuda()
+    yb = g.forward(xd, seed=7, sample0=0).clone()
+    for i in range(3):
+        yi = g.forward(xd[i:i + 1].contiguous(), seed=7, sample0=i)
+        assert relerr(yi[0].cpu(), yb[i].cpu()) <= (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_generator_rng_dropout_matches_exported_mask(dtype):
+    """kernel-RNG dropout == explicit-mask dropout with the mask cfd_dropout_mask exports"""
+    from cfd_amd import nets, ops
+    g = nets.Generator("U", dtype=dtype, seed=5)
+    x, _, _ = inputs(2)
+    xd = torch.from_numpy(x).cuda()
+    y_rng = g.forward(xd, seed=11, sample0=5).clone()
+    masks = [ops.dropout_mask(s, 0.5, 11 * 16 + i, sample0=5) for i, s in enumerate(g.dropout_shapes(2), 1)]
+    keep = float(torch.stack([m.float().mean() for m in masks]).mean())
+    assert 0.49 < keep < 0.51
+    y_mask = g.forward(xd, masks=masks)
+    assert torch.equal(y_rng, y_mask)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("training", [True, False])
+def test_discriminator_forward(training, dtype):
+    from cfd_amd import nets
+    po = O.init_discriminator(seed=11, jitter=True)
+    po["c3.bn.moving_mean"] = 0.05 * torch.randn(512, generator=torch.Generator().manual_seed(1))
+    po["c3.bn.moving_var"] = 1 + 0.1 * torch.rand(512, generator=torch.Generator().manual_seed(2))
+    d = nets.Discriminator(dtype=dtype)
+    d.params.load_keras(O.to_numpy(po))
+    x, u, _ = inputs(2)
+    with torch.no_grad():
+        ref = O.discriminator_forward(po, x, u, training)
+        ref_logits = O.discriminator_forward(po, x, u, training, return_logits=True)
+    y = d.forward(torch.from_numpy(x).cuda(), torch.from_numpy(u).cuda(), training)
+    logits = d.forward(torch.from_numpy(x).cuda(), torch.from_numpy(u).cuda(), training, want_logits=True)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape == (2, 4, 32, 1)
+    print(f"discriminator training={training} {dtype}: {relerr(y.cpu(), ref):.3e} logits {relerr(logits.cpu(), ref_logits):.3e}")
+    assert relerr(y.cpu(), ref) <= TOL[dtype]
+    assert relerr(logits.cpu(), ref_logits) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cnn_forward(dtype):
+    from cfd_amd import nets
+    po = O.init_cnn(seed=12, jitter=True)
+    c = nets.CnnRegressor(dtype=dtype)
+    c.params.load_keras(O.to_numpy(po))
+    x, _, _ = inputs(3)
+    with torch.no_grad():
+        ref = O.cnn_forward(po, x)
+    y = c.forward(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    print(f"cnn {dtype}: {relerr(y.cpu(), ref):.3e}", y.flatten().tolist(), ref.flatten().tolist())
+    assert relerr(y.cpu(), ref) <= TOL[dtype]
+
+
+def test_keras_layout_round_trip():
+    from cfd_amd import nets
+    po = O.to_numpy(O.init_generator("P", seed=3, jitter=True))
+    g = nets.Generator("P", dtype=torch.bfloat16)
+    g.params.load_keras(po)
+    back = g.params.to_keras()
+    assert set(back) == set(po)
+    for k in po:
+        assert np.array_equal(back[k], po[k]), k
