@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the CFD-surrogate hot path on MI355X (contract: task statement ④).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B]
+
+One "step" = one pass of the hot path over one batch of synthetic geometries resident in HBM.
+Workloads (BASELINE.json configs):
+  infer_pd_fp32   (default, configs[1]) P generator + DeltaP CNN batched inference, fp32 MFMA
+  infer_all_bf16  (configs[2])          U + P generators + DeltaP CNN batched inference, bf16 MFMA
+Cases are independent, so N GPUs shard them with no data-path collective ("scaling": "weak").
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# MI355X peaks (MI355X_MICROARCH.md): dense MFMA TFLOP/s by arithmetic type, HBM GB/s
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+PEAK_HBM_GBS = 8000.0
+# forward GFLOP per sample of the GEMM-shaped layers only (SURVEY.md §2.1 minus the direct first/last layers)
+WORKLOADS = {
+    "infer_pd_fp32": dict(nets=["P", "DeltaP"], dtype="f32", batch=32),
+    "infer_all_bf16": dict(nets=["U", "P", "DeltaP"], dtype="bf16", batch=64),
+}
+
+
+def dist_setup(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return rank, world, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def build_nets(names, tdt):
+    from cfd_amd import nets
+    out = {}
+    for n in names:
+        if n in ("U", "P"):
+            out[n] = nets.Generator(n, dtype=tdt, seed=hash(n) % 97)
+        else:
+            out[n] = nets.CnnRegressor(dtype=tdt, seed=5)
+    return out
+
+
+def run_step(models, x, step, sample0):
+    for name, m in models.items():
+        if name == "DeltaP":
+            m.forward(x)
+        else:
+            m.forward(x, seed=step, sample0=sample0)
+
+
+def cpu_baseline(names, seconds_budget=20.0):
+    """The oracle (PyTorch-CPU fp32 restatement of the Keras graphs) on the host cores, batch 1 per
+    predict call like the reference's valid.py loop.  Reported only."""
+    from oracle import nets as O
+    from cfd_amd import synthetic
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(cores)
+    params = {}
+    for n in names:
+        params[n] = O.init_cnn(seed=5) if n == "DeltaP" else O.init_generator(n, seed=3)
+    x, _, _ = synthetic.model_batch([0])
+    masks = {n: [torch.ones(s) for s in O.generator_dropout_shapes(n, 1)] for n in names if n != "DeltaP"}
+
+    def one():
+        with torch.no_grad():
+            for n in names:
+                if n == "DeltaP":
+                    O.cnn_forward(params[n], x)
+                else:
+                    O.generator_forward(params[n], x, n, masks[n])
+    one()  # warm-up
+    t0 = time.perf_counter()
+    n_done = 0
+    while True:
+        one()
+        n_done += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n_done >= 64:
+            break
+    return dict(value=n_done / el, unit="samples/s", cores=cores, kind="port",
+                sample=f"{n_done} synthetic 64x512 cases, batch 1 per call, nets {'+'.join(names)}, oracle (PyTorch-CPU fp32)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="infer_pd_fp32", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = dist_setup(args.gpus)
+    wl = WORKLOADS[args.workload]
+    B = args.batch or wl["batch"]
+    tdt = torch.float32 if wl["dtype"] == "f32" else torch.bfloat16
+
+    from cfd_amd import ops, synthetic
+    models = build_nets(wl["nets"], tdt)
+    # synthetic geometries of the reference shape, resident in HBM before the timed region
+    xs, _, _ = synthetic.model_batch([rank * B + i for i in range(B)])
+    x = torch.from_numpy(xs).cuda()
+
+    for s in range(args.warmup):
+        run_step(models, x, s, rank * B)
+    barrier(world)
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        run_step(models, x, args.warmup + s, rank * B)
+    barrier(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel (igemm): HIP events around every launch, same workload
+    roof = None
+    if rank == 0:
+        with ops.KernelTimer() as kt:
+            for s in range(min(args.steps, 5)):
+                run_step(models, x, 1000 + s, 0)
+        sm = kt.summary()
+        achieved = sm["total_flops"] / (sm["total_ms"] * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[wl["dtype"]]
+        roof = dict(bound="mfma", kernel="igemm_kernel", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
+                    frac=round(achieved / peak, 4), traffic=None,
+                    launches_per_step=sm["launches"] // min(args.steps, 5),
+                    avg_launch_us=round(sm["total_ms"] * 1e3 / sm["launches"], 2))
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        out = {
+            "metric": "surrogate samples/sec (infer + train) at 1/2/4/8 GPUs; field rel-err vs CPU ref",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
+            "config": {"workload": args.workload, "nets": wl["nets"], "per_gpu_batch": B,
+                       "global_batch": B * world, "grid": "64x512", "parallelism": f"case-sharded x{world}, no collectives"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl["nets"])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,6 +61,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise CfdError(f"{LIB_PATH} is missing: build it with `python -m cfd_amd.build` "
                        "(the HIP library is the only compute path; there is no fallback)")
+    # torch ships its own libamdhip64; import it FIRST so that this library binds to the same HIP
+    # runtime (same soname) instead of pulling a second copy from /opt/rocm -- two runtimes in one
+    # process do not share devices, streams or allocations.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

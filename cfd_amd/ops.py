@@ -62,6 +62,33 @@ def conv_out_shape(kind: int, B: int, Hi: int, Wi: int, cout: int):
 _ws_cache = {}
 
 
+class KernelTimer:
+    """Brackets every cfd_conv_forward launch with HIP events on the launch stream (torch's current
+    stream IS the stream the kernels are launched on) and records their algorithmic FLOPs.
+    Used by bench.py for the `roofline` object; off by default (zero overhead)."""
+
+    def __init__(self):
+        self.records = []   # (tag, flops, start_event, end_event)
+
+    def __enter__(self):
+        global _timer
+        _timer = self
+        return self
+
+    def __exit__(self, *a):
+        global _timer
+        _timer = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        tot_ms = sum(s.elapsed_time(e) for _, _, s, e in self.records)
+        tot_fl = sum(f for _, f, _, _ in self.records)
+        return dict(launches=len(self.records), total_ms=tot_ms, total_flops=tot_fl)
+
+
+_timer: Optional[KernelTimer] = None
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only fp32 scratch per device (split-K slabs, tap buffers)."""
     key = (device.index if device.index is not None else torch.cuda.current_device())
@@ -99,7 +126,15 @@ def conv_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
         if nbytes < 0:
             check(-1, "cfd_conv_workspace_bytes")
         ws = _workspace(nbytes, x.device)
+    if _timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.cfd_conv_forward(C.byref(d), xp, _ptr(w), _ptr(bias), yp, _ptr(ws), _stream()), "cfd_conv_forward")
+    if _timer is not None:
+        e1.record()
+        taps = {CONV_K4S2: 16, CONV_K4S1: 16, CONV_K3S1: 9, CONVT_K4S2: 4, DENSE: 1}[kind]
+        opix = out.numel() // cout
+        _timer.records.append((kind, 2.0 * opix * cout * taps * cin, e0, e1))
     return out
 
 
