@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcfd_amd.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-CONV_K4S2, CONV_K4S1, CONV_K3S1, CONVT_K4S2, DENSE = 0, 1, 2, 3, 4
+CONV_K4S2, CONV_K4S1, CONV_K3S1, CONVT_K4S2, DENSE, CONV_K4S1_BWD = 0, 1, 2, 3, 4, 5
 
 
 class ConvDesc(C.Structure):
@@ -46,6 +46,23 @@ SIGNATURES = {
     "cfd_dropout_mask": (_i, [_vp, _i64, _i, _i, _i, _f, C.c_uint64, _vp]),
     "cfd_maxpool2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cfd_cast_copy": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
+    "cfd_conv_wgrad": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
+    "cfd_conv_wgrad_suggest_split": (_i, [C.POINTER(ConvDesc)]),
+    "cfd_transpose_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "cfd_colsum": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp]),
+    "cfd_bn_act_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _f, C.c_uint64, _i64, _vp, _i, _vp,
+                            _vp, _i, _i, _i, _f, _i, _i, _f, _i, _vp]),
+    "cfd_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _i, _f, _i, _vp]),
+    "cfd_maxpool2_act_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cfd_dropout_apply": (_i, [_vp, _vp, _vp, _i64, _f, C.c_uint64, _i64, _i, _vp]),
+    "cfd_bce_logits": (_i, [_vp, _vp, _f, _i64, _vp, _vp, _f, _vp]),
+    "cfd_field_loss": (_i, [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp, _i, _vp]),
+    "cfd_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _f, _vp]),
+    "cfd_bn_update_moving": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "cfd_tap_scatter_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "cfd_tap_dx": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
+    "cfd_tap_dw": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp]),
+    "cfd_conv_first_wgrad": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cfd_resample_workspace_bytes": (_i64, [_i, _i, _i]),
     "cfd_resample_nearest": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _d, _d, _d, _vp, _vp, _vp]),
 }

@@ -124,6 +124,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
       dy = kh - 1; dx = kw - 1; wtap = t;
     } else if (p.kind == CFD_DENSE) {
       dy = 0; dx = 0; wtap = 0;
+    } else if (p.kind == CFD_CONV_K4S1_BWD) {
+      dy = (t >> 2) - 2; dx = (t & 3) - 2; wtap = t;   // pad 2 before / 1 after: data gradient of the k4 s1 'same' conv
     } else {
       dy = (t >> 2) - 1; dx = (t & 3) - 1; wtap = t;
     }
@@ -298,7 +300,8 @@ static int fill_params(const cfd_conv_desc *d, IgemmParams &p) {
     case CFD_CONV_K4S2:
       CFD_REQUIRE(d->Hi % 2 == 0 && d->Wi % 2 == 0, "k4s2 'same' path needs even input (got %dx%d)", d->Hi, d->Wi);
       p.Ho = d->Hi / 2; p.Wo = d->Wi / 2; p.Hq = p.Ho; p.Wq = p.Wo; p.ntaps = 16; break;
-    case CFD_CONV_K4S1: p.Ho = d->Hi; p.Wo = d->Wi; p.Hq = p.Ho; p.Wq = p.Wo; p.ntaps = 16; break;
+    case CFD_CONV_K4S1:
+    case CFD_CONV_K4S1_BWD: p.Ho = d->Hi; p.Wo = d->Wi; p.Hq = p.Ho; p.Wq = p.Wo; p.ntaps = 16; break;
     case CFD_CONV_K3S1: p.Ho = d->Hi; p.Wo = d->Wi; p.Hq = p.Ho; p.Wq = p.Wo; p.ntaps = 9; break;
     case CFD_CONVT_K4S2:
       p.Ho = d->Hi * 2; p.Wo = d->Wi * 2; p.Hq = d->Hi; p.Wq = d->Wi; p.ntaps = 4; p.nclass = 4; break;

@@ -283,3 +283,154 @@ def resample_nearest(cases, height: int = 64, width: int = 512, device="cuda", r
         # numpy: np.interp raises "array of sample points is empty" (:210)
         raise ValueError("array of sample points is empty")
     return out if return_device else out.cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------
+# training-step kernels (backward, losses, optimiser)
+# ----------------------------------------------------------------------------------------
+from ._lib import CONV_K4S1_BWD  # noqa: E402
+
+_TAPS = {CONV_K4S2: 16, CONV_K4S1: 16, CONV_K3S1: 9, CONVT_K4S2: 16, DENSE: 1, CONV_K4S1_BWD: 16}
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kind: int, cout: int, dw: torch.Tensor,
+               split_m: Optional[int] = None) -> torch.Tensor:
+    """dw[Cout][taps][Cin] (fp32 view of the flat gradient buffer) for the FORWARD layer (kind, x -> dy)."""
+    lib = _lib.load()
+    if kind == DENSE:
+        B, cin = x.shape
+        Hi = Wi = 1
+    else:
+        B, Hi, Wi, cin = x.shape
+    xp, ldx = _nhwc(x)
+    yp, ldy = _nhwc(dy)
+    if x.dtype != dy.dtype:
+        raise _lib.CfdError("wgrad: x and dy must share the compute dtype")
+    d = ConvDesc(kind=kind, dtype=_DT[x.dtype], out_dtype=_DT[x.dtype], B=B, Hi=Hi, Wi=Wi, Cin=cin, Cout=cout,
+                 ldx=ldx, ldy=ldy, act=0, leaky_slope=0.0, split_k=1)
+    s = int(split_m) if split_m else lib.cfd_conv_wgrad_suggest_split(C.byref(d))
+    if s > 1:
+        dw.zero_()  # memset node on the stream; the kernel accumulates with atomics
+    if _timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.cfd_conv_wgrad(C.byref(d), xp, yp, _ptr(dw), s, _stream()), "cfd_conv_wgrad")
+    if _timer is not None:
+        e1.record()
+        opix = (dy.numel() // cout) if kind != CONVT_K4S2 else (x.numel() // cin)
+        _timer.records.append((100 + kind, 2.0 * opix * cout * _TAPS[kind] * cin, e0, e1))
+    return dw
+
+
+def transpose_weight(w: torch.Tensor, flip: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[Cout][taps][Cin] -> [Cin][taps'][Cout] (taps reversed if flip): operand of the data-gradient GEMM."""
+    cout, cin = w.shape[0], w.shape[-1]
+    taps = w.numel() // (cout * cin)
+    if out is None:
+        out = torch.empty((cin,) + tuple(w.shape[1:-1]) + (cout,), dtype=w.dtype, device=w.device)
+    check(_lib.load().cfd_transpose_weight(_ptr(w), _ptr(out), cout, taps, cin, int(flip), _DT[w.dtype], _stream()),
+          "cfd_transpose_weight")
+    return out
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    xp, ldx = _nhwc(x)
+    Cc = x.shape[-1]
+    check(_lib.load().cfd_colsum(xp, ldx, _ptr(out), x.numel() // Cc, Cc, _DT[x.dtype], _stream()), "cfd_colsum")
+    return out
+
+
+def bn_act_bwd(x, mean, var, gamma, beta, g1, act1, dx, dgamma, dbeta, g2=None, act2=ACT_RELU, drop_mask=None,
+               drop_rate=0.0, drop_seed=0, sample0=0, eps=1e-3, slope=LEAKY_SLOPE):
+    B, H, W, Cc = x.shape
+    xp, ldx = _nhwc(x)
+    g1p, ldg1 = _nhwc(g1)
+    g2p, ldg2 = (None, 0) if g2 is None else _nhwc(g2)
+    dxp, lddx = (None, 0) if dx is None else _nhwc(dx)
+    if drop_mask is not None and drop_rate == 0.0:
+        drop_rate = 0.5
+    check(_lib.load().cfd_bn_act_bwd(xp, ldx, _DT[x.dtype], _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), g1p, ldg1,
+                                     g2p, ldg2, _ptr(drop_mask), drop_rate, drop_seed, sample0, dxp, lddx,
+                                     _ptr(dgamma), _ptr(dbeta), B, H * W, Cc, eps, act1, act2, slope, _DT[g1.dtype],
+                                     _stream()), "cfd_bn_act_bwd")
+    return dx
+
+
+def act_bwd(y, g1, act1, dx, g2=None, act2=ACT_RELU, slope=LEAKY_SLOPE):
+    yp, ldy = _nhwc(y)
+    g1p, ldg1 = _nhwc(g1)
+    g2p, ldg2 = (None, 0) if g2 is None else _nhwc(g2)
+    dxp, lddx = _nhwc(dx)
+    Cc = y.shape[-1]
+    check(_lib.load().cfd_act_bwd(yp, ldy, g1p, ldg1, g2p, ldg2, dxp, lddx, y.numel() // Cc, Cc, act1, act2, slope,
+                                  _DT[y.dtype], _stream()), "cfd_act_bwd")
+    return dx
+
+
+def maxpool2_act_bwd(x, dy, dx, act, slope=LEAKY_SLOPE):
+    B, H, W, Cc = x.shape
+    check(_lib.load().cfd_maxpool2_act_bwd(_ptr(x), _ptr(dy), _ptr(dx), B, H, W, Cc, act, slope, _DT[x.dtype],
+                                           _stream()), "cfd_maxpool2_act_bwd")
+    return dx
+
+
+def dropout_apply(x, out, rate=0.5, mask=None, seed=0, elem0=0):
+    check(_lib.load().cfd_dropout_apply(_ptr(x), _ptr(out), _ptr(mask), x.numel(), rate, seed, elem0, _DT[x.dtype],
+                                        _stream()), "cfd_dropout_apply")
+    return out
+
+
+def bce_logits(z, loss, dz=None, target=None, target_const=1.0, grad_scale=1.0):
+    check(_lib.load().cfd_bce_logits(_ptr(z), _ptr(target), float(target_const), z.numel(), _ptr(loss), _ptr(dz),
+                                     float(grad_scale), _stream()), "cfd_bce_logits")
+
+
+MAE, MSE, HUBER = 0, 1, 2
+
+
+def field_loss(y, target, kind, loss, dout=None, weight=1.0, delta=1.0, dy_extra=None, sigmoid_grad=False):
+    check(_lib.load().cfd_field_loss(_ptr(y), _ptr(target), y.numel(), kind, float(delta), float(weight), _ptr(loss),
+                                     _ptr(dy_extra), _ptr(dout), int(sigmoid_grad), _stream()), "cfd_field_loss")
+
+
+def adam_step(w, g, m, v, w_compute, alpha, beta1, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    n = w.numel()
+    cdt = BF16 if (w_compute is not None and w_compute.dtype == torch.bfloat16) else F32
+    wc = w_compute if cdt == BF16 else None
+    check(_lib.load().cfd_adam_step(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(wc), cdt, n, float(alpha), float(beta1),
+                                    float(beta2), float(eps), float(grad_scale), _stream()), "cfd_adam_step")
+
+
+def bn_update_moving(mm, mv, mean, var, momentum=0.99):
+    B, Cc = mean.shape
+    check(_lib.load().cfd_bn_update_moving(_ptr(mm), _ptr(mv), _ptr(mean), _ptr(var), B, Cc, momentum, _stream()),
+          "cfd_bn_update_moving")
+
+
+def tap_scatter_grad(dz, dtaps, B, Hi, Wi, geom):
+    check(_lib.load().cfd_tap_scatter_grad(_ptr(dz), _ptr(dtaps), B, Hi, Wi, geom, _stream()), "cfd_tap_scatter_grad")
+
+
+def tap_dx(d, w, dx, ntaps):
+    dxp, lddx = _nhwc(dx)
+    Cc = dx.shape[-1]
+    check(_lib.load().cfd_tap_dx(_ptr(d), _ptr(w), dxp, lddx, dx.numel() // Cc, Cc, ntaps, _DT[dx.dtype], _stream()),
+          "cfd_tap_dx")
+    return dx
+
+
+def tap_dw(d, x, dw, ntaps):
+    xp, ldx = _nhwc(x)
+    Cc = x.shape[-1]
+    check(_lib.load().cfd_tap_dw(_ptr(d), xp, ldx, _ptr(dw), x.numel() // Cc, Cc, ntaps, _DT[x.dtype], _stream()),
+          "cfd_tap_dw")
+    return dw
+
+
+def conv_first_wgrad(x, x2, dpre, dw, db, ksize, stride):
+    B, Hi, Wi, c1 = x.shape
+    c2 = 0 if x2 is None else x2.shape[-1]
+    dp, ldd = _nhwc(dpre)
+    check(_lib.load().cfd_conv_first_wgrad(_ptr(x), _ptr(x2), c1, c2, dp, ldd, _ptr(dw), _ptr(db), B, Hi, Wi,
+                                           dpre.shape[-1], ksize, stride, _DT[dpre.dtype], _stream()),
+          "cfd_conv_first_wgrad")

@@ -48,6 +48,7 @@ typedef enum {
   CFD_CONV_K3S1 = 2,  /* Conv2D 3x3 stride 1 'same' (pad 1,1)              out = in   */
   CFD_CONVT_K4S2 = 3, /* Conv2DTranspose 4x4 stride 2 'same'                out = 2*in */
   CFD_DENSE = 4       /* Dense: Hi=Wi=1, Cin = features in                             */
+  /* 5 = CFD_CONV_K4S1_BWD, see the training section */
 } cfd_conv_kind;
 
 typedef struct {
@@ -128,6 +129,79 @@ int cfd_maxpool2(const void *x, void *y, int B, int Hi, int Wi, int C, int dtype
 /* dtype conversion / strided channel copy: y[p][0..C) = convert(x[p][0..C)) */
 int cfd_cast_copy(const void *x, int ldx, int x_dtype, void *y, int ldy, int y_dtype, int64_t pixels, int C,
                   void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Training step: what Keras runs inside train_on_batch (U/train.py:121-125, P/train.py:133-137,
+ * DeltaP/train.py:131) for the graphs above -- backward of every layer, losses, Adam.
+ * Data gradients of the GEMM-shaped layers reuse cfd_conv_forward on transposed weights:
+ *   dX of CONV_K4S2  = CONVT_K4S2(dY, Wt)      dX of CONVT_K4S2 = CONV_K4S2(dY, Wt)
+ *   dX of CONV_K3S1  = CONV_K3S1(dY, Wt flipped)   dX of DENSE = DENSE(dY, Wt)
+ *   dX of CONV_K4S1  = CFD_CONV_K4S1_BWD(dY, Wt flipped)   (4x4 stride 1, pad 2 before / 1 after)
+ * with Wt[ci][tap'][co] = W[co][tap][ci] from cfd_transpose_weight.
+ * ---------------------------------------------------------------------------------- */
+#define CFD_CONV_K4S1_BWD 5
+
+/* dW[Cout][taps][Cin] (fp32) = sum over pixels of dY (x) gathered X, on MFMA; `desc` describes the FORWARD
+ * layer (x = its input, dy = gradient of its output, dtype of both = desc->dtype).  split_m == 1 stores,
+ * > 1 accumulates with atomics into a buffer the caller zeroed. */
+int cfd_conv_wgrad(const cfd_conv_desc *desc, const void *x, const void *dy, float *dw, int split_m, void *stream);
+int cfd_conv_wgrad_suggest_split(const cfd_conv_desc *desc);
+/* dst[Cin][taps][Cout] = src[Cout][taps][Cin], taps reversed when flip != 0 */
+int cfd_transpose_weight(const void *src, void *dst, int Cout, int taps, int Cin, int flip, int dtype, void *stream);
+/* out[c] += sum_m x[m][c]: bias gradients (out must be zeroed by the caller) */
+int cfd_colsum(const void *x, int ldx, float *out, int64_t M, int C, int dtype, void *stream);
+
+/* Backward of cfd_bn_act (BatchNorm batch statistics per sample + dropout + activation(s)):
+ *   g1 = dL/dy, g2 = dL/dy2 (may be NULL);  dx = dL/dx (`dtype`, may be NULL);  dgamma/dbeta fp32 [C] are
+ *   ACCUMULATED (atomics; zero them first).  mean/var: the fp32 [B][C] statistics the forward wrote. */
+int cfd_bn_act_bwd(const void *x, int ldx, int x_dtype, const float *mean, const float *var, const float *gamma,
+                   const float *beta, const void *g1, int ldg1, const void *g2, int ldg2, const uint8_t *drop_mask,
+                   float drop_rate, uint64_t drop_seed, int64_t sample0, void *dx, int lddx, float *dgamma,
+                   float *dbeta, int B, int HW, int C, float eps, int act1, int act2, float leaky_slope, int dtype,
+                   void *stream);
+/* layers without BN: dpre = g1*act1'(y) + g2*act2'(y), y = the saved activation (its sign decides) */
+int cfd_act_bwd(const void *y, int ldy, const void *g1, int ldg1, const void *g2, int ldg2, void *dx, int lddx,
+                int64_t pixels, int C, int act1, int act2, float leaky_slope, int dtype, void *stream);
+/* MaxPooling2D(2,2) backward fused with the activation backward of the layer that fed the pool;
+ * x = that layer's activation [B][Hi][Wi][C], dy = gradient of the pooled tensor, dx = gradient of its pre-activation */
+int cfd_maxpool2_act_bwd(const void *x, const void *dy, void *dx, int B, int Hi, int Wi, int C, int act,
+                         float leaky_slope, int dtype, void *stream);
+/* Dropout(rate) on a dense tensor (fc1 output, DeltaP/models/generator.py:42) and on its gradient */
+int cfd_dropout_apply(const void *x, void *y, const uint8_t *mask, int64_t total, float rate, uint64_t seed,
+                      int64_t elem0, int dtype, void *stream);
+
+/* Losses, mean over all n elements, with gradients.  loss (fp32 scalar, device) is ACCUMULATED.
+ * binary_crossentropy on the logits of a sigmoid output (discriminator.py:42,48; generator.py:93):
+ *   target = target[i] or the constant; dz = grad_scale*(sigmoid(z)-t)/n (dz may be NULL) */
+int cfd_bce_logits(const float *z, const float *target, float target_const, int64_t n, float *loss, float *dz,
+                   float grad_scale, void *stream);
+/* kind 0: MAE ('mae' / MC_mae, loss.py:47-88, whose mass-conservation term is identically 0), 1: MSE
+ * (MC_mse, loss.py:4-45), 2: Huber(delta) (DeltaP generator.py:53).  dout = (weight*l'(y-t)/n + dy_extra) *
+ * (sigmoid_grad ? y(1-y) : 1): the gradient w.r.t. the logits of a sigmoid output (or w.r.t. y). */
+int cfd_field_loss(const float *y, const float *target, int64_t n, int kind, float delta, float weight, float *loss,
+                   const float *dy_extra, float *dout, int sigmoid_grad, void *stream);
+
+/* Adam, Keras form (epsilon outside the sqrt): m += (g-m)(1-b1); v += (g^2-v)(1-b2); w -= alpha*m/(sqrt(v)+eps),
+ * g scaled by grad_scale first (1/world after an all-reduce SUM).  alpha = lr*sqrt(1-b2^t)/(1-b1^t) from the host.
+ * w_compute (may be NULL): the bf16 shadow copy of w, refreshed in the same pass. */
+int cfd_adam_step(float *w, const float *g, float *m, float *v, void *w_compute, int compute_dtype, int64_t n,
+                  float alpha, float beta1, float beta2, float eps, float grad_scale, void *stream);
+/* moving = moving*momentum + batch*(1-momentum), once per sample in order (BatchNormalization momentum 0.99) */
+int cfd_bn_update_moving(float *moving_mean, float *moving_var, const float *mean, const float *var, int B, int C,
+                         float momentum, void *stream);
+
+/* One-output-channel layers (generator `out` Conv2DTranspose, discriminator c6 Conv2D): backward.
+ * geom 0: Conv2DTranspose k4 s2; geom 1: Conv2D k4 s1 'same'.  dtaps fp32 [B*Hi*Wi][16]. */
+int cfd_tap_scatter_grad(const float *dz, float *dtaps, int B, int Hi, int Wi, int geom, void *stream);
+/* dx[row][c] = sum_t d[row][t]*w[t][c]  (ntaps = 16, or 1 for the Dense(1) layer fc3) */
+int cfd_tap_dx(const float *d, const void *w, void *dx, int lddx, int64_t rows, int C, int ntaps, int dtype,
+               void *stream);
+/* dw[t][c] += sum_rows d[row][t]*x[row][c]  (fp32, accumulated) */
+int cfd_tap_dw(const float *d, const void *x, int ldx, float *dw, int64_t rows, int C, int ntaps, int dtype,
+               void *stream);
+/* first layers (Cin <= 2): dw[Cout][k][k][Cin] and db[Cout] accumulated from dpre (`dtype`, stride ldd) */
+int cfd_conv_first_wgrad(const float *x, const float *x2, int cin1, int cin2, const void *dpre, int ldd, float *dw,
+                         float *db, int B, int Hi, int Wi, int Cout, int ksize, int stride, int dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Nearest-neighbour resample + wall mask, fp64, bit-exact.
