@@ -88,6 +88,7 @@ class Generator(_Net):
             c = f + s
         specs += [Spec("out.kernel", "convT", (4, 4, 1, c)), Spec("out.bias", "vec", (1,))]
         super().__init__(specs, device, dtype, seed)
+        self.params.no_transpose = frozenset({"e1.kernel", "out.kernel"})
 
     def dropout_shapes(self, B: int):
         h, w, out = self.H // 64, self.W // 64, []
@@ -150,6 +151,75 @@ class Generator(_Net):
             g = cats[i - 1]
         return ops.convT_out(g, P.c("out.kernel"), P.m("out.bias"), apply_sigmoid=True, want_logits=want_logits)
 
+    def backward(self, dz: torch.Tensor, x: torch.Tensor, masks: Optional[List[torch.Tensor]] = None, seed: int = 0,
+                 sample0: int = 0) -> None:
+        """Backward of the forward that JUST ran with the same (x, masks, seed, sample0): dz = dL/dlogits fp32
+        (B,H,W,1).  Writes every trainable gradient of the generator into params.grad (bias gradients of
+        convolutions followed by BatchNorm are identically zero and stay at the zero the step memset wrote)."""
+        P, a, B = self.params, self.a, x.shape[0]
+        pl = self.plan(B)
+        enc, dec = a["enc"], a["dec"]
+        skips = enc[::-1]
+        dt = self.dtype
+        # ---- output layer (Conv2DTranspose to one channel): taps family
+        cat5 = pl["cat5"]
+        _, h5, w5, c5 = cat5.shape
+        dtaps = self.buf(pl, "dtaps", (B * h5 * w5, 16), torch.float32)
+        ops.tap_scatter_grad(dz, dtaps, B, h5, w5, 0)
+        ops.tap_dw(dtaps, cat5, P.g("out.kernel"), 16)
+        ops.colsum(dz.view(-1, 1), P.g("out.bias"))
+        dcat = self.buf(pl, "dcat5", cat5.shape)
+        ops.tap_dx(dtaps, P.c("out.kernel"), dcat, 16)
+        # ---- decoder, last block first
+        nd = len(dec)
+        mi = sum(1 for _f, d in dec if d)
+        skip_grads = {}
+        for i in range(nd, 0, -1):
+            f, drop = dec[i - 1]
+            cat_i = pl[f"cat{i}"]
+            raw = pl[f"raw_d{i}"]
+            skip_grads[6 - i] = dcat[..., f:]          # gradient of the ReLU copy of e_{6-i}
+            mask, rate = None, 0.0
+            if drop:
+                mi -= 1
+                rate = DROP_RATE
+                if masks is not None:
+                    mask = masks[mi]
+            draw = self.buf(pl, f"draw_d{i}", raw.shape)
+            ops.bn_act_bwd(raw, pl[f"mean_d{i}"], pl[f"var_d{i}"], P.m(f"d{i}.bn.gamma"), P.m(f"d{i}.bn.beta"),
+                           dcat[..., :f], ACT_RELU, draw, P.g(f"d{i}.bn.gamma"), P.g(f"d{i}.bn.beta"),
+                           drop_mask=mask, drop_rate=rate, drop_seed=seed * 16 + i, sample0=sample0, eps=BN_EPS)
+            g_in = pl[f"cat{i - 1}"] if i > 1 else pl["b"]
+            ops.conv_wgrad(g_in, draw, CONVT_K4S2, f, P.g(f"d{i}.kernel"))
+            dnext = self.buf(pl, f"dcat{i - 1}" if i > 1 else "db", g_in.shape)
+            ops.conv_forward(draw, P.t(f"d{i}.kernel"), None, CONV_K4S2, g_in.shape[-1], out=dnext)
+            dcat = dnext
+        # ---- bottleneck: conv + ReLU (no BN)
+        b = pl["b"]
+        dpre = self.buf(pl, "dpre_b", b.shape)
+        ops.act_bwd(b, dcat, ACT_RELU, dpre)
+        e5 = pl["e5"]
+        ops.conv_wgrad(e5, dpre, CONV_K4S2, a["bott"], P.g("b.kernel"))
+        ops.colsum(dpre, P.g("b.bias"))
+        de = self.buf(pl, "de5", e5.shape)
+        ops.conv_forward(dpre, P.t("b.kernel"), None, CONVT_K4S2, e5.shape[-1], out=de)
+        # ---- encoder, deepest first: gradient arrives through the next conv (LeakyReLU) and the skip (ReLU)
+        for i in range(5, 1, -1):
+            f = enc[i - 1]
+            raw = pl[f"raw_e{i}"]
+            draw = self.buf(pl, f"draw_e{i}", raw.shape)
+            ops.bn_act_bwd(raw, pl[f"mean_e{i}"], pl[f"var_e{i}"], P.m(f"e{i}.bn.gamma"), P.m(f"e{i}.bn.beta"),
+                           de, ACT_LEAKY, draw, P.g(f"e{i}.bn.gamma"), P.g(f"e{i}.bn.beta"),
+                           g2=skip_grads[i], act2=ACT_RELU, eps=BN_EPS)
+            e_prev = pl[f"e{i - 1}"]
+            ops.conv_wgrad(e_prev, draw, CONV_K4S2, f, P.g(f"e{i}.kernel"))
+            de = self.buf(pl, f"de{i - 1}", e_prev.shape)
+            ops.conv_forward(draw, P.t(f"e{i}.kernel"), None, CONVT_K4S2, e_prev.shape[-1], out=de)
+        e1 = pl["e1"]
+        dpre1 = self.buf(pl, "dpre_e1", e1.shape)
+        ops.act_bwd(e1, de, ACT_LEAKY, dpre1, g2=skip_grads[1], act2=ACT_RELU)
+        ops.conv_first_wgrad(x, None, dpre1, P.g("e1.kernel"), P.g("e1.bias"), 4, 2)
+
 
 class Discriminator(_Net):
     def __init__(self, image_shape=(64, 512, 1), device="cuda", dtype=torch.bfloat16, seed: int = 1):
@@ -162,6 +232,8 @@ class Discriminator(_Net):
             c = f
         specs += [Spec("c6.kernel", "conv", (4, 4, c, 1)), Spec("c6.bias", "vec", (1,))]
         super().__init__(specs, device, dtype, seed)
+        self.params.no_transpose = frozenset({"c1.kernel", "c6.kernel"})
+        self.params.flip_taps = frozenset({"c5.kernel"})
 
     @property
     def patch_shape(self):
@@ -196,6 +268,55 @@ class Discriminator(_Net):
         ops.conv_forward(d, P.c("c6.kernel"), P.m("c6.bias"), CONV_K4S1, 1, act=ACT_SIGMOID, out=out)
         return out
 
+    def update_moving(self, B: int) -> None:
+        """moving statistics <- batch statistics of the forward that just ran (momentum 0.99)"""
+        pl = self.plan(B)
+        for i in range(2, 6):
+            ops.bn_update_moving(self.params.m(f"c{i}.bn.moving_mean"), self.params.m(f"c{i}.bn.moving_var"),
+                                 pl[f"mean_c{i}"], pl[f"var_c{i}"])
+
+    def backward(self, dlogits: torch.Tensor, src: torch.Tensor, tgt: torch.Tensor, train_convs: bool = True,
+                 want_input_grad: bool = False):
+        """Backward of the training-mode forward that JUST ran on (src, tgt).  train_convs=False is the
+        composite-GAN case: only BatchNorm gamma/beta receive gradients (U/models/generator.py:79-81) and the
+        gradient w.r.t. the target image (the generator's output) is returned as fp32 (B,H,W,1)."""
+        P, B = self.params, src.shape[0]
+        pl = self.plan(B)
+        c5 = pl["c5"]
+        _, h, w, cc = c5.shape
+        dtaps = self.buf(pl, "dtaps", (B * h * w, 16), torch.float32)
+        ops.tap_scatter_grad(dlogits, dtaps, B, h, w, 1)
+        if train_convs:
+            ops.tap_dw(dtaps, c5, P.g("c6.kernel"), 16)
+            ops.colsum(dlogits.view(-1, 1), P.g("c6.bias"))
+        dc = self.buf(pl, "dc5", c5.shape)
+        ops.tap_dx(dtaps, P.c("c6.kernel"), dc, 16)
+        for i in range(5, 1, -1):
+            f, s, _bn = DISC[i - 1]
+            raw = pl[f"raw_c{i}"]
+            draw = self.buf(pl, f"draw_c{i}", raw.shape)
+            ops.bn_act_bwd(raw, pl[f"mean_c{i}"], pl[f"var_c{i}"], P.m(f"c{i}.bn.gamma"), P.m(f"c{i}.bn.beta"),
+                           dc, ACT_LEAKY, draw, P.g(f"c{i}.bn.gamma"), P.g(f"c{i}.bn.beta"), eps=BN_EPS)
+            prev = pl[f"c{i - 1}"]
+            kind = CONV_K4S2 if s == 2 else CONV_K4S1
+            if train_convs:
+                ops.conv_wgrad(prev, draw, kind, f, P.g(f"c{i}.kernel"))
+            dc = self.buf(pl, f"dc{i - 1}", prev.shape)
+            ops.conv_forward(draw, P.t(f"c{i}.kernel"), None, CONVT_K4S2 if s == 2 else ops.CONV_K4S1_BWD,
+                             prev.shape[-1], out=dc)
+        c1 = pl["c1"]
+        dpre1 = self.buf(pl, "dpre_c1", c1.shape)
+        ops.act_bwd(c1, dc, ACT_LEAKY, dpre1)
+        if train_convs:
+            ops.conv_first_wgrad(src, tgt, dpre1, P.g("c1.kernel"), P.g("c1.bias"), 4, 2)
+        if not want_input_grad:
+            return None
+        # d(target image): a transposed conv of dpre1 to ONE channel with w[tap][co] = W[co][tap][ci=1]
+        wt = self.buf(pl, "w_c1_tgt", (16, DISC[0][0]))
+        ops.cast_copy(P.m("c1.kernel")[..., 1].permute(1, 2, 0).reshape(1, 1, 16, DISC[0][0]).contiguous(),
+                      wt.view(1, 1, 16, DISC[0][0]))
+        return ops.convT_out(dpre1, wt, None, apply_sigmoid=False)
+
 
 class CnnRegressor(_Net):
     def __init__(self, image_shape=(64, 512, 1), device="cuda", dtype=torch.bfloat16, seed: int = 2):
@@ -209,30 +330,89 @@ class CnnRegressor(_Net):
         for name, ci, co in (("fc1", flat, 256), ("fc2", 256, 128), ("fc3", 128, 1)):
             specs += [Spec(name + ".kernel", "dense", (ci, co)), Spec(name + ".bias", "vec", (co,))]
         super().__init__(specs, device, dtype, seed)
+        self.params.no_transpose = frozenset({"g1.kernel", "fc3.kernel"})
 
-    def forward(self, x: torch.Tensor, drop_mask: Optional[torch.Tensor] = None):
-        """x fp32 (B,H,W,1) -> fp32 (B,1).  Dropout(0.5) after fc1 only when a mask is given (training)."""
+    def forward(self, x: torch.Tensor, training: bool = False, drop_mask: Optional[torch.Tensor] = None,
+                seed: int = 0, sample0: int = 0):
+        """x fp32 (B,H,W,1) -> fp32 (B,1).  Dropout(0.5) after fc1 only in training (explicit uint8 (B,256)
+        mask, or the kernel RNG keyed by (seed, sample0))."""
         P, B = self.params, x.shape[0]
         pl = self.plan(B)
         H, W = self.H, self.W
         g1 = self.buf(pl, "g1", (B, H, W, 64))
         ops.conv_first(x, None, P.m("g1.kernel"), P.m("g1.bias"), 64, 3, 1, ACT_LEAKY, self.dtype, out=g1)
-        g2 = ops.maxpool2(g1)
+        g2 = pl["g2"] = ops.maxpool2(g1)
         g3 = self.buf(pl, "g3", (B, H // 2, W // 2, 128))
         ops.conv_forward(g2, P.c("g3.kernel"), P.m("g3.bias"), CONV_K3S1, 128, act=ACT_RELU, out=g3)
         g4 = self.buf(pl, "g4", (B, H // 2, W // 2, 256))
         ops.conv_forward(g3, P.c("g4.kernel"), P.m("g4.bias"), CONV_K3S1, 256, act=ACT_RELU, out=g4)
-        g5 = ops.maxpool2(g4)
+        g5 = pl["g5"] = ops.maxpool2(g4)
         g6 = self.buf(pl, "g6", (B, H // 4, W // 4, 512))
         ops.conv_forward(g5, P.c("g6.kernel"), P.m("g6.bias"), CONV_K3S1, 512, act=ACT_RELU, out=g6)
-        g7 = ops.maxpool2(g6)
+        g7 = pl["g7"] = ops.maxpool2(g6)
         flat = g7.view(B, -1)  # Flatten in (H,W,C) order == NHWC memory order
         f1 = self.buf(pl, "fc1", (B, 256))
         ops.conv_forward(flat, P.c("fc1.kernel"), P.m("fc1.bias"), DENSE, 256, act=ACT_RELU, out=f1)
-        if drop_mask is not None:
-            raise NotImplementedError("training-time dropout is applied by the train step")
+        f1d = f1
+        if training:
+            f1d = self.buf(pl, "fc1_drop", (B, 256))
+            ops.dropout_apply(f1, f1d, DROP_RATE, mask=drop_mask, seed=seed, elem0=sample0 * 256)
+        pl["fc1_in"] = f1d
         f2 = self.buf(pl, "fc2", (B, 128))
-        ops.conv_forward(f1, P.c("fc2.kernel"), P.m("fc2.bias"), DENSE, 128, act=ACT_RELU, out=f2)
+        ops.conv_forward(f1d, P.c("fc2.kernel"), P.m("fc2.bias"), DENSE, 128, act=ACT_RELU, out=f2)
         y = self.buf(pl, "y", (B, 1), torch.float32)
         ops.conv_forward(f2, P.c("fc3.kernel"), P.m("fc3.bias"), DENSE, 1, act=ACT_NONE, out=y)
         return y
+
+    def backward(self, dy: torch.Tensor, x: torch.Tensor, drop_mask: Optional[torch.Tensor] = None, seed: int = 0,
+                 sample0: int = 0) -> None:
+        """Backward of the training forward that JUST ran; dy = dL/dy fp32 (B,1)."""
+        P, B = self.params, x.shape[0]
+        pl = self.plan(B)
+        dt = self.dtype
+        H, W = self.H, self.W
+        f2, f1d, f1 = pl["fc2"], pl["fc1_in"], pl["fc1"]
+        # fc3 (one output): small-K kernels
+        ops.tap_dw(dy, f2.view(B, 1, 1, 128), P.g("fc3.kernel"), 1)
+        ops.colsum(dy, P.g("fc3.bias"))
+        df2 = self.buf(pl, "dfc2", (B, 128))
+        ops.tap_dx(dy, P.c("fc3.kernel"), df2.view(B, 1, 1, 128), 1)
+        dpre2 = self.buf(pl, "dpre_fc2", (B, 128))
+        ops.act_bwd(f2.view(B, 1, 1, 128), df2.view(B, 1, 1, 128), ACT_RELU, dpre2.view(B, 1, 1, 128))
+        ops.conv_wgrad(f1d, dpre2, DENSE, 128, P.g("fc2.kernel"))
+        ops.colsum(dpre2, P.g("fc2.bias"))
+        df1d = self.buf(pl, "dfc1d", (B, 256))
+        ops.conv_forward(dpre2, P.t("fc2.kernel"), None, DENSE, 256, out=df1d)
+        df1 = self.buf(pl, "dfc1", (B, 256))
+        ops.dropout_apply(df1d, df1, DROP_RATE, mask=drop_mask, seed=seed, elem0=sample0 * 256)
+        dpre1 = self.buf(pl, "dpre_fc1", (B, 256))
+        ops.act_bwd(f1.view(B, 1, 1, 256), df1.view(B, 1, 1, 256), ACT_RELU, dpre1.view(B, 1, 1, 256))
+        g7 = pl["g7"]
+        flat = g7.view(B, -1)
+        ops.conv_wgrad(flat, dpre1, DENSE, 256, P.g("fc1.kernel"))
+        ops.colsum(dpre1, P.g("fc1.bias"))
+        dg7 = self.buf(pl, "dg7", g7.shape)
+        ops.conv_forward(dpre1, P.t("fc1.kernel"), None, DENSE, flat.shape[1], out=dg7.view(B, -1))
+        # g6 -> pool: pool backward fused with g6's ReLU backward
+        g6, g5, g4, g3, g2, g1 = pl["g6"], pl["g5"], pl["g4"], pl["g3"], pl["g2"], pl["g1"]
+        dpre6 = self.buf(pl, "dpre_g6", g6.shape)
+        ops.maxpool2_act_bwd(g6, dg7, dpre6, ACT_RELU)
+        ops.conv_wgrad(g5, dpre6, CONV_K3S1, 512, P.g("g6.kernel"))
+        ops.colsum(dpre6, P.g("g6.bias"))
+        dg5 = self.buf(pl, "dg5", g5.shape)
+        ops.conv_forward(dpre6, P.t("g6.kernel"), None, CONV_K3S1, 256, out=dg5)
+        dpre4 = self.buf(pl, "dpre_g4", g4.shape)
+        ops.maxpool2_act_bwd(g4, dg5, dpre4, ACT_RELU)
+        ops.conv_wgrad(g3, dpre4, CONV_K3S1, 256, P.g("g4.kernel"))
+        ops.colsum(dpre4, P.g("g4.bias"))
+        dg3 = self.buf(pl, "dg3", g3.shape)
+        ops.conv_forward(dpre4, P.t("g4.kernel"), None, CONV_K3S1, 128, out=dg3)
+        dpre3 = self.buf(pl, "dpre_g3", g3.shape)
+        ops.act_bwd(g3, dg3, ACT_RELU, dpre3)
+        ops.conv_wgrad(g2, dpre3, CONV_K3S1, 128, P.g("g3.kernel"))
+        ops.colsum(dpre3, P.g("g3.bias"))
+        dg2 = self.buf(pl, "dg2", g2.shape)
+        ops.conv_forward(dpre3, P.t("g3.kernel"), None, CONV_K3S1, 64, out=dg2)
+        dpre1c = self.buf(pl, "dpre_g1", g1.shape)
+        ops.maxpool2_act_bwd(g1, dg2, dpre1c, ACT_LEAKY)
+        ops.conv_first_wgrad(x, None, dpre1c, P.g("g1.kernel"), P.g("g1.bias"), 3, 1)

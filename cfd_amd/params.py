@@ -78,6 +78,36 @@ class ParamStore:
         s = self.specs[name]
         return self.compute[s.offset:s.offset + s.numel].view(s.packed_shape)
 
+    # ---- training state -----------------------------------------------------------------
+    def enable_training(self) -> None:
+        """allocate the flat gradient buffer and the transposed compute-dtype weights used by the
+        data-gradient GEMMs (dX of a conv = forward kernel on Wt[ci][taps][co])"""
+        if getattr(self, "grad", None) is None:
+            self.grad = torch.zeros(self.n_trainable, dtype=torch.float32, device=self.device)
+            self.compute_t = torch.zeros(self.n_main, dtype=self.compute_dtype, device=self.device)
+            self.refresh_transposed()
+
+    def g(self, name: str) -> torch.Tensor:
+        s = self.specs[name]
+        return self.grad[s.offset:s.offset + s.numel].view(s.packed_shape)
+
+    def t(self, name: str) -> torch.Tensor:
+        """transposed weights [Cin][taps][Cout] (taps flipped for the stride-1 convs) in the compute dtype"""
+        s = self.specs[name]
+        shp = (s.packed_shape[-1],) + tuple(s.packed_shape[1:-1]) + (s.packed_shape[0],)
+        return self.compute_t[s.offset:s.offset + s.numel].view(shp)
+
+    def refresh_transposed(self) -> None:
+        if getattr(self, "compute_t", None) is None:
+            return
+        for name, s in self.specs.items():
+            if s.kind in ("conv", "convT", "dense") and name not in self.no_transpose:
+                flip = s.kind == "conv" and s.packed_shape[1] * s.packed_shape[2] in (9,) or name in self.flip_taps
+                ops.transpose_weight(self.c(name), bool(flip), out=self.t(name))
+
+    no_transpose: frozenset = frozenset()
+    flip_taps: frozenset = frozenset()
+
     def refresh_compute(self) -> None:
         """compute copy <- master (after loading weights; the fused Adam kernel keeps it in sync later)"""
         if self.compute is not self.master:

@@ -1,0 +1,175 @@
+"""GPU parity of whole training steps (forward, backward, Adam, moving statistics) against the oracle's
+autograd steps on identical weights, inputs and dropout masks."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as O
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(y, ref):
+    y, ref = torch.as_tensor(y).double().cpu(), torch.as_tensor(ref).double().cpu()
+    return float((y - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def rel_l2(y, ref):
+    y, ref = torch.as_tensor(y).double().cpu(), torch.as_tensor(ref).double().cpu()
+    return float((y - ref).norm() / ref.norm().clamp_min(1e-30))
+
+
+def inputs(B, seed0=0):
+    from cfd_amd import synthetic
+    return synthetic.model_batch(range(seed0, seed0 + B))
+
+
+def grads_keras(net):
+    """the flat gradient buffer exported in Keras layouts (same transform as the weights)"""
+    P = net.params
+    saved = P.master
+    tmp = torch.zeros_like(P.master)
+    tmp[:P.n_trainable] = P.grad
+    P.master = tmp
+    try:
+        return P.to_keras()
+    finally:
+        P.master = saved
+
+
+def compare_grads(gk, ref_grads, prefix, tol, skip_bias_of_bn=True, report=None):
+    worst = 0.0
+    for k, g in ref_grads.items():
+        if not k.startswith(prefix):
+            continue
+        name = k[len(prefix):]
+        mine = torch.from_numpy(gk[name])
+        gr = g.detach()
+        if gr.abs().max() < 1e-6 * max(1.0, float(mine.abs().max())) or \
+                (name.endswith(".bias") and (name[:-5] + ".bn.gamma") in gk):
+            # bias before BatchNorm: the true gradient is 0; the oracle holds rounding noise, we hold exact zeros
+            assert float(mine.abs().max()) <= 1e-4, name
+            continue
+        e = rel_l2(mine, gr)
+        worst = max(worst, e)
+        if report is not None:
+            report.append((name, e))
+        assert e <= tol, f"{name}: rel L2 {e:.3e} > {tol}"
+    return worst
+
+
+def check_adam_delta(mine, ref_after, ref_before, lr, keys, dtype):
+    """the first Adam step is ~lr*sign(g) per element; compare the applied updates, tolerating the few
+    elements whose near-zero gradient changes sign with the summation order"""
+    for k in keys:
+        dm = torch.from_numpy(mine[k]).double() - ref_before[k].double()
+        dr = ref_after[k].double() - ref_before[k].double()
+        bad = ((dm - dr).abs() > 0.5 * lr).double().mean().item()
+        assert bad <= (0.01 if dtype == torch.float32 else 0.08), (k, bad)
+        assert float((dm.abs().mean() / lr)) > 0.1, k   # the step really happened
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 1.5e-1)])
+def test_d_train_on_batch(dtype, tol):
+    from cfd_amd import nets, trainer
+    B = 2
+    po = O.init_discriminator(seed=21, jitter=True)
+    d = nets.Discriminator(dtype=dtype)
+    d.params.load_keras(O.to_numpy(po))
+    tr = trainer.DiscriminatorTrainer(d)
+    x, u, _ = inputs(B)
+    opt = O.KerasAdam(2e-3, 0.5)
+    w0 = {k: v.clone() for k, v in po.items()}
+    for step, label in enumerate((1.0, 0.0)):
+        lab = np.full((B, 4, 32, 1), label, dtype=np.float32)
+        loss_ref, gref = O.d_train_on_batch(po, opt, x, u, lab, return_grads=True)
+        loss = tr.train_on_batch(torch.from_numpy(x).cuda(), torch.from_numpy(u).cuda(), label)
+        if step == 0:
+            assert abs(loss - loss_ref) <= (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, abs(loss_ref))
+            rep = []
+            w = compare_grads(grads_keras(d), gref, "", tol, report=rep)
+            print(f"D step {step} {dtype}: loss {loss:.6f} vs {loss_ref:.6f}, worst grad rel-L2 {w:.3e}",
+                  ", ".join(f"{n}={e:.1e}" for n, e in rep))
+            wk = d.params.to_keras()
+            check_adam_delta(wk, po, w0, 2e-3, ("c2.kernel", "c5.kernel", "c3.bn.gamma", "c6.kernel"), dtype)
+            for k in ("c4.bn.moving_mean", "c4.bn.moving_var", "c2.bn.moving_mean"):   # momentum-0.99 update
+                dm = torch.from_numpy(wk[k]) - w0[k]
+                assert rel_l2(dm, po[k] - w0[k]) <= (1e-3 if dtype == torch.float32 else 5e-2), k
+        else:
+            # Adam's first step moves every weight by ~lr*sign(g): elements whose tiny gradient differs in sign
+            # between two fp32 evaluation orders land 2*lr apart, so later steps agree only loosely
+            assert abs(loss - loss_ref) <= 5e-2 * max(1.0, abs(loss_ref)), (loss, loss_ref)
+
+
+# Gradient tolerances are rel-L2 per tensor.  They are looser than the forward tolerance for a structural
+# reason: every ReLU/LeakyReLU derivative is a step function of the pre-activation, and an element whose
+# pre-activation rounds to the other side of zero (fp32: ~1e-6 of them, bf16: ~3e-3 of them per layer)
+# changes that element's gradient by O(1).  The error therefore grows with depth (printed per tensor).
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-2), (torch.bfloat16, 3.5e-1)])
+@pytest.mark.parametrize("arch", ["U", "P"])
+def test_gan_train_on_batch(arch, dtype, tol):
+    from cfd_amd import nets, trainer
+    B = 2
+    pg = O.init_generator(arch, seed=22, jitter=True)
+    pd = O.init_discriminator(seed=23, jitter=True)
+    g = nets.Generator(arch, dtype=dtype)
+    d = nets.Discriminator(dtype=dtype)
+    g.params.load_keras(O.to_numpy(pg))
+    d.params.load_keras(O.to_numpy(pd))
+    tr = trainer.GanTrainer(g, d)
+    x, u, _ = inputs(B)
+    gen = torch.Generator().manual_seed(3)
+    masks = [(torch.rand(s, generator=gen) < 0.5) for s in O.generator_dropout_shapes(arch, B)]
+    opt = O.KerasAdam(4e-4, 0.5)
+    pg0 = {k: v.clone() for k, v in pg.items()}
+    pd0 = {k: v.clone() for k, v in pd.items()}
+    lab = np.ones((B, 4, 32, 1), dtype=np.float32)
+    ref, gref = O.gan_train_on_batch(pg, pd, opt, arch, x, lab, u, [m.float() for m in masks], return_grads=True)
+    out = tr.train_on_batch(torch.from_numpy(x).cuda(), 1.0, torch.from_numpy(u).cuda(),
+                            masks=[m.to(torch.uint8).cuda() for m in masks])
+    ltol = 1e-4 if dtype == torch.float32 else 3e-2
+    for a, b in zip(out, ref):
+        assert abs(a - b) <= ltol * max(1.0, abs(b)), (out, ref)
+    rep = []
+    wg = compare_grads(grads_keras(g), gref, "g.", tol, report=rep)
+    wd = compare_grads(grads_keras(d), {k: v for k, v in gref.items() if k.startswith("d.")}, "d.", tol)
+    print(f"GAN {arch} {dtype}: losses {out} vs {ref}; worst grad rel-L2 G {wg:.3e} D-bn {wd:.3e}")
+    print("   per-tensor:", ", ".join(f"{n}={e:.1e}" for n, e in rep))
+    # after the Adam step: G weights moved like the oracle's; D conv weights untouched
+    check_adam_delta(g.params.to_keras(), pg, pg0, 4e-4, ("e2.kernel", "d3.kernel", "d5.bn.gamma", "out.kernel"), dtype)
+    dk = d.params.to_keras()
+    check_adam_delta(dk, pd, pd0, 4e-4, ("c3.bn.gamma",), dtype)
+    assert np.array_equal(dk["c3.kernel"], pd0["c3.kernel"].numpy())   # D's convs are frozen inside the GAN
+    # test_on_batch: D on moving statistics
+    t_ref = O.gan_test_on_batch(pg, pd, arch, x, lab, u, [m.float() for m in masks])
+    t_out = tr.test_on_batch(torch.from_numpy(x).cuda(), 1.0, torch.from_numpy(u).cuda(),
+                             masks=[m.to(torch.uint8).cuda() for m in masks])
+    for a, b in zip(t_out, t_ref):
+        assert abs(a - b) <= 5e-2 * max(1.0, abs(b)), (t_out, t_ref)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 3.5e-1)])
+def test_cnn_train_on_batch(dtype, tol):
+    from cfd_amd import nets, trainer
+    B = 3
+    po = O.init_cnn(seed=24, jitter=True)
+    c = nets.CnnRegressor(dtype=dtype)
+    c.params.load_keras(O.to_numpy(po))
+    tr = trainer.CnnTrainer(c)
+    x, _, _ = inputs(B)
+    y = np.array([[0.3], [0.9], [0.1]], dtype=np.float32)
+    mask = torch.rand((B, 256), generator=torch.Generator().manual_seed(1)) < 0.5
+    opt = O.KerasAdam(1e-3, 0.5)
+    po0 = {k: v.clone() for k, v in po.items()}
+    loss_ref, gref = O.cnn_train_on_batch(po, opt, x, y, mask.float(), return_grads=True)
+    loss = tr.train_on_batch(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(),
+                             drop_mask=mask.to(torch.uint8).cuda())
+    assert abs(loss - loss_ref) <= (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    rep = []
+    w = compare_grads(grads_keras(c), gref, "", tol, report=rep)
+    print(f"CNN {dtype}: loss {loss:.5f} vs {loss_ref:.5f}; worst grad rel-L2 {w:.3e}",
+          ", ".join(f"{n}={e:.1e}" for n, e in rep))
+    check_adam_delta(c.params.to_keras(), po, po0, 1e-3, ("g3.kernel", "g6.kernel", "fc2.kernel"), dtype)
+    v_ref = 100.0 * float(O.huber(y, O.cnn_forward(po, x)))
+    v = tr.test_on_batch(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+    assert abs(v - v_ref) <= 5e-2 * max(1.0, abs(v_ref))
