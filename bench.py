@@ -29,6 +29,10 @@ PEAK_HBM_GBS = 8000.0
 WORKLOADS = {
     "infer_pd_fp32": dict(nets=["P", "DeltaP"], dtype="f32", batch=32),
     "infer_all_bf16": dict(nets=["U", "P", "DeltaP"], dtype="bf16", batch=64),
+    # configs[3]: U surrogate training, bf16, data parallel; one step = the reference's four calls
+    # (U/train.py:119-125): G predict, D on real, D on fake, composite GAN update -- incl. Adam and all-reduce
+    "train_u_bf16": dict(nets=["U", "D"], dtype="bf16", batch=16, train=True),
+    "train_u_fp32": dict(nets=["U", "D"], dtype="f32", batch=4, train=True),
 }
 
 
@@ -59,6 +63,21 @@ def build_nets(names, tdt):
         else:
             out[n] = nets.CnnRegressor(dtype=tdt, seed=5)
     return out
+
+
+class TrainJob:
+    def __init__(self, tdt):
+        from cfd_amd import nets, trainer
+        self.g = nets.Generator("U", dtype=tdt, seed=7)
+        self.d = nets.Discriminator(dtype=tdt, seed=8)
+        self.dtr = trainer.DiscriminatorTrainer(self.d)
+        self.gtr = trainer.GanTrainer(self.g, self.d)
+
+    def step(self, x, y, step, sample0):
+        fake = self.g.forward(x, seed=2 * step, sample0=sample0)          # generate_fake_samples (utils.py:52-62)
+        self.dtr.train_on_batch(x, y, 1.0)                                # d_model.train_on_batch([A,B], ones)
+        self.dtr.train_on_batch(x, fake, 0.0)                             # d_model.train_on_batch([A,fake], zeros)
+        return self.gtr.train_on_batch(x, 1.0, y, seed=2 * step + 1, sample0=sample0)   # gan_model.train_on_batch
 
 
 def run_step(models, x, step, sample0):
@@ -102,6 +121,36 @@ def cpu_baseline(names, seconds_budget=20.0):
                 sample=f"{n_done} synthetic 64x512 cases, batch 1 per call, nets {'+'.join(names)}, oracle (PyTorch-CPU fp32)")
 
 
+def cpu_baseline_train(seconds_budget=25.0):
+    """The oracle's U training step (batch 1, reference order U/train.py:116-125) on the host cores."""
+    from oracle import nets as O
+    from cfd_amd import synthetic
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(cores)
+    pg, pd = O.init_generator("U", seed=3), O.init_discriminator(seed=4)
+    od, og = O.KerasAdam(2e-3, 0.5), O.KerasAdam(4e-4, 0.5)
+    x, u, _ = synthetic.model_batch([0])
+    ones, zeros = np.ones((1, 4, 32, 1), np.float32), np.zeros((1, 4, 32, 1), np.float32)
+    masks = [torch.ones(s) for s in O.generator_dropout_shapes("U", 1)]
+
+    def one():
+        with torch.no_grad():
+            fake = O.generator_forward(pg, x, "U", masks).numpy()
+        O.d_train_on_batch(pd, od, x, u, ones)
+        O.d_train_on_batch(pd, od, x, fake, zeros)
+        O.gan_train_on_batch(pg, pd, og, "U", x, ones, u, masks)
+    one()
+    t0, n = time.perf_counter(), 0
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 16:
+            break
+    return dict(value=n / el, unit="samples/s", cores=cores, kind="port",
+                sample=f"{n} U training steps at batch 1 (G predict + 2 D updates + GAN update), oracle (PyTorch-CPU fp32)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,10 +167,20 @@ def main():
     tdt = torch.float32 if wl["dtype"] == "f32" else torch.bfloat16
 
     from cfd_amd import ops, synthetic
-    models = build_nets(wl["nets"], tdt)
     # synthetic geometries of the reference shape, resident in HBM before the timed region
-    xs, _, _ = synthetic.model_batch([rank * B + i for i in range(B)])
+    xs, us, _ = synthetic.model_batch([rank * B + i for i in range(B)])
     x = torch.from_numpy(xs).cuda()
+    train = wl.get("train", False)
+    if train:
+        job = TrainJob(tdt)
+        y = torch.from_numpy(us).cuda()
+        models = None
+
+        def run_step(_m, xx, step, sample0):   # noqa: F811  (same signature as the inference step)
+            job.step(xx, y, step, sample0)
+    else:
+        run_step = globals()["run_step"]
+        models = build_nets(wl["nets"], tdt)
 
     for s in range(args.warmup):
         run_step(models, x, s, rank * B)
@@ -146,7 +205,7 @@ def main():
         sm = kt.summary()
         achieved = sm["total_flops"] / (sm["total_ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[wl["dtype"]]
-        roof = dict(bound="mfma", kernel="igemm_kernel", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
+        roof = dict(bound="mfma", kernel="igemm_kernel+wgrad_kernel" if train else "igemm_kernel", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
                     frac=round(achieved / peak, 4), traffic=None,
                     launches_per_step=sm["launches"] // min(args.steps, 5),
                     avg_launch_us=round(sm["total_ms"] * 1e3 / sm["launches"], 2))
@@ -159,11 +218,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
             "config": {"workload": args.workload, "nets": wl["nets"], "per_gpu_batch": B,
-                       "global_batch": B * world, "grid": "64x512", "parallelism": f"case-sharded x{world}, no collectives"},
+                       "global_batch": B * world, "grid": "64x512", "parallelism": (f"dp{world}, RCCL gradient all-reduce" if train else f"case-sharded x{world}, no collectives")},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl["nets"])
+            out["cpu_baseline"] = cpu_baseline_train() if train else cpu_baseline(wl["nets"])
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

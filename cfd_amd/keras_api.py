@@ -1,0 +1,390 @@
+"""Host-side mirror of the reference's model boundary.
+
+The reference's entry scripts touch their Keras models through a handful of names only:
+
+  constructors  define_generator(image_shape)            U/models/generator.py:44, P/models/generator.py:69
+                define_discriminator(image_shape)        U/models/discriminator.py:12
+                define_gan(g_model, d_model, image_shape) U/models/generator.py:77, P/models/generator.py:117
+                define_cnn_model(image_shape)            DeltaP/models/generator.py:15
+  methods       .predict(x) .train_on_batch(x, y) .test_on_batch(x, y) .output_shape .layers .summary()
+                (U/train.py:41,121-125,148; utils.py:56; U/valid.py:29)
+  persistence   save_model(model, path, overwrite=True, include_optimizer=True), load_model(path, compile=...)
+                (U/train.py:156,199-203,214-216; U/valid.py:39)
+  losses        MC_mse, MC_mae, MC_huber_loss            U/models/loss.py
+
+Same names, same argument meaning, numpy NHWC fp32 in / numpy out, Python exceptions on error.
+Everything below the method calls runs on the HIP kernels (cfd_amd.nets / cfd_amd.trainer).
+
+Environment switches (opt-in, the defaults reproduce the reference):
+  CFD_AMD_DTYPE = bf16 | fp32   compute dtype of the MFMA kernels (default bf16)
+"""
+from __future__ import annotations
+
+import io
+import json
+import os
+import zipfile
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import nets, ops, trainer
+
+
+def _dtype() -> torch.dtype:
+    return {"bf16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32}[
+        os.environ.get("CFD_AMD_DTYPE", "bf16").lower()]
+
+
+def _dev(a) -> torch.Tensor:
+    """numpy / list-of-one-numpy (Keras accepts both, utils.py:56) -> fp32 device tensor"""
+    if isinstance(a, (list, tuple)):
+        if len(a) != 1:
+            raise ValueError(f"expected one input array, got {len(a)}")
+        a = a[0]
+    if isinstance(a, torch.Tensor):
+        return a.to("cuda", torch.float32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+class Layer:
+    """what `define_gan` iterates over: `for layer in d_model.layers: if not isinstance(layer, BatchNormalization):
+    layer.trainable = False` (U/models/generator.py:79-81)"""
+
+    def __init__(self, name: str):
+        self.name, self.trainable = name, True
+
+
+class BatchNormalization(Layer):
+    pass
+
+
+class Conv2D(Layer):
+    pass
+
+
+class Conv2DTranspose(Layer):
+    pass
+
+
+class Dense(Layer):
+    pass
+
+
+class Model:
+    kind = "model"
+
+    def __init__(self, net, image_shape):
+        self.net = net
+        self.image_shape = tuple(image_shape)
+        self.layers: List[Layer] = []
+        self._seed = int.from_bytes(os.urandom(4), "little")   # dropout is random run to run, as in Keras
+        self.compiled = True
+
+    # -- Keras surface ---------------------------------------------------------------------
+    def count_params(self) -> int:
+        return sum(s.numel for s in self.net.params.specs.values())
+
+    def summary(self, print_fn=print):
+        print_fn(f'Model: "{self.kind}"  input {(None,) + self.image_shape}  output {self.output_shape}')
+        for name, s in self.net.params.specs.items():
+            print_fn(f"  {name:28s} {str(s.keras_shape):24s} {s.numel:>12,d}")
+        print_fn(f"Total params: {self.count_params():,d}")
+
+    def get_weights_dict(self):
+        return self.net.params.to_keras()
+
+    def set_weights_dict(self, w):
+        self.net.params.load_keras(w)
+        self.net.params.refresh_transposed()
+
+    def _next_seed(self) -> int:
+        self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) % (1 << 62)
+        return self._seed >> 8
+
+
+class GeneratorModel(Model):
+    kind = "generator"
+
+    def __init__(self, arch: str, image_shape):
+        super().__init__(nets.Generator(arch, image_shape, dtype=_dtype(), seed=int.from_bytes(os.urandom(4), "little")),
+                         image_shape)
+        self.arch = arch
+        self.layers = [Layer(n) for n in self.net.params.specs if n.endswith(".kernel")]
+
+    @property
+    def output_shape(self):
+        return (None,) + self.image_shape
+
+    def predict(self, x, verbose=0, batch_size=None):
+        """BatchNorm and Dropout run in training mode here too (they are built with training=True,
+        generator.py:21,33,36): per-sample statistics, fresh dropout draw per call."""
+        xd = _dev(x)
+        return self.net.forward(xd, seed=self._next_seed()).cpu().numpy()
+
+    __call__ = predict
+
+
+class DiscriminatorModel(Model):
+    kind = "discriminator"
+
+    def __init__(self, image_shape):
+        super().__init__(nets.Discriminator(image_shape, dtype=_dtype(), seed=int.from_bytes(os.urandom(4), "little")),
+                         image_shape)
+        self.layers = []
+        for i in range(1, 7):
+            self.layers.append(Conv2D(f"c{i}"))
+            if 2 <= i <= 5:
+                self.layers.append(BatchNormalization(f"c{i}.bn"))
+        self._trainer: Optional[trainer.DiscriminatorTrainer] = None
+
+    @property
+    def output_shape(self):
+        return (None,) + self.net.patch_shape
+
+    def _tr(self):
+        if self._trainer is None:
+            # compiled in define_discriminator BEFORE define_gan freezes the conv layers, so D's own step
+            # trains everything (Keras-2 / pix2pix behaviour; see oracle/keras_semantics.py)
+            self._trainer = trainer.DiscriminatorTrainer(self.net, lr=2e-3, beta_1=0.5, train_convs=True)
+        return self._trainer
+
+    @staticmethod
+    def _label(y) -> float:
+        y = np.asarray(y)
+        v = float(y.flat[0])
+        if not np.all(y == v):
+            raise NotImplementedError("patch labels must be constant (the reference uses all-ones / all-zeros)")
+        return v
+
+    def train_on_batch(self, x, y):
+        a, b = x
+        return self._tr().train_on_batch(_dev(a), _dev(b), self._label(y))
+
+    def predict(self, x, verbose=0):
+        a, b = x
+        return self.net.forward(_dev(a), _dev(b), training=False).cpu().numpy()
+
+
+class GanModel(Model):
+    kind = "gan"
+
+    def __init__(self, g_model: GeneratorModel, d_model: DiscriminatorModel, image_shape):
+        self.g_model, self.d_model = g_model, d_model
+        self.image_shape = tuple(image_shape)
+        self.layers = [g_model, d_model]
+        self.net = g_model.net
+        self._seed = g_model._seed
+        self.compiled = True
+        self._trainer = trainer.GanTrainer(g_model.net, d_model.net, lr=4e-4, beta_1=0.5, field_loss=ops.MAE,
+                                           field_weight=100.0)
+
+    @property
+    def output_shape(self):
+        return [self.d_model.output_shape, self.g_model.output_shape]
+
+    def count_params(self):
+        return self.g_model.count_params() + self.d_model.count_params()
+
+    def train_on_batch(self, x, y):
+        """x = [A]; y = [patch labels, B] -> [total, bce, mae] (U/train.py:125)"""
+        y_patch, y_field = y
+        return self._trainer.train_on_batch(_dev(x), DiscriminatorModel._label(y_patch), _dev(y_field),
+                                            seed=self.g_model._next_seed())
+
+    def test_on_batch(self, x, y):
+        y_patch, y_field = y
+        return self._trainer.test_on_batch(_dev(x), DiscriminatorModel._label(y_patch), _dev(y_field),
+                                           seed=self.g_model._next_seed())
+
+    def predict(self, x, verbose=0):
+        fake = self.g_model.predict(x)
+        return [self.d_model.predict([x[0] if isinstance(x, (list, tuple)) else x, fake]), fake]
+
+
+class CnnModel(Model):
+    kind = "cnn"
+
+    def __init__(self, image_shape):
+        super().__init__(nets.CnnRegressor(image_shape, dtype=_dtype(), seed=int.from_bytes(os.urandom(4), "little")),
+                         image_shape)
+        self.layers = [Layer(n) for n in self.net.params.specs if n.endswith(".kernel")]
+        self._trainer: Optional[trainer.CnnTrainer] = None
+
+    @property
+    def output_shape(self):
+        return (None, 1)
+
+    def _tr(self):
+        if self._trainer is None:
+            self._trainer = trainer.CnnTrainer(self.net, lr=1e-3, beta_1=0.5, weight=100.0, delta=1.0)
+        return self._trainer
+
+    def predict(self, x, verbose=0):
+        return self.net.forward(_dev(x), training=False).cpu().numpy()
+
+    def train_on_batch(self, x, y):
+        return self._tr().train_on_batch(_dev(x), _dev(y).reshape(-1, 1), seed=self._next_seed())
+
+    def test_on_batch(self, x, y):
+        return self._tr().test_on_batch(_dev(x), _dev(y).reshape(-1, 1))
+
+
+# ---- constructors with the reference's signatures -------------------------------------------
+def define_generator_U(image_shape=(64, 512, 1)):
+    return GeneratorModel("U", image_shape)
+
+
+def define_generator_P(image_shape=(64, 512, 1)):
+    return GeneratorModel("P", image_shape)
+
+
+def define_discriminator(image_shape=(64, 512, 1)):
+    return DiscriminatorModel(image_shape)
+
+
+def define_gan(g_model, d_model, image_shape):
+    for layer in d_model.layers:                       # the reference's loop, kept for its side effect on .trainable
+        if not isinstance(layer, BatchNormalization):
+            layer.trainable = False
+    return GanModel(g_model, d_model, image_shape)
+
+
+def define_cnn_model(image_shape=(64, 512, 1)):
+    return CnnModel(image_shape)
+
+
+# ---- losses exported by `from models import *` (U/models/loss.py) -----------------------------
+def _loss(kind, y_true, y_pred, delta=1.0) -> float:
+    yt, yp = _dev(y_true).reshape(-1), _dev(y_pred).reshape(-1)
+    acc = torch.zeros(1, dtype=torch.float32, device="cuda")
+    ops.field_loss(yp, yt, kind, acc, None, delta=delta)
+    return float(acc.item())
+
+
+def MC_mse(y_true, y_pred):
+    """MSE; the reference's mass-conservation term is computed from y_true on both sides and is 0 (loss.py:13-37)"""
+    return _loss(ops.MSE, y_true, y_pred)
+
+
+def MC_mae(y_true, y_pred):
+    return _loss(ops.MAE, y_true, y_pred)
+
+
+def MC_huber_loss(y_true, y_pred, delta=1.0):
+    return _loss(ops.HUBER, y_true, y_pred, delta)
+
+
+# ---- persistence ------------------------------------------------------------------------------
+FORMAT = "cfd_amd.keras-archive.v1"
+
+
+def _npz_bytes(arrays: dict) -> bytes:
+    bio = io.BytesIO()
+    np.savez(bio, **arrays)
+    return bio.getvalue()
+
+
+def _opt_state(opt: Optional[trainer.Adam], prefix: str) -> dict:
+    if opt is None:
+        return {}
+    return {prefix + "m": opt.m.cpu().numpy(), prefix + "v": opt.v.cpu().numpy(),
+            prefix + "t": np.array([opt.t], dtype=np.int64)}
+
+
+def _load_opt(opt: trainer.Adam, z, prefix: str) -> None:
+    if prefix + "m" in z:
+        opt.m.copy_(torch.from_numpy(z[prefix + "m"]))
+        opt.v.copy_(torch.from_numpy(z[prefix + "v"]))
+        opt.t = int(z[prefix + "t"][0])
+
+
+def save_model(model, filepath, overwrite=True, include_optimizer=True):
+    """Same call as keras.models.save_model; same file names (`*.keras`, a zip archive as in Keras 3).
+    Members: config.json, metadata.json (as Keras writes) and `model.weights.npz` holding the weights in KERAS
+    layouts (Conv2D (kh,kw,Cin,Cout), Conv2DTranspose (kh,kw,Cout,Cin), Dense (in,out)) plus `optimizer.npz`.
+    Keras itself stores the weights as HDF5 (`model.weights.h5`); h5py is not available in this environment, so
+    files are interchangeable with real Keras only through the npz member (documented in DESIGN.md)."""
+    filepath = str(filepath)
+    if os.path.exists(filepath) and not overwrite:
+        raise FileExistsError(filepath)
+    os.makedirs(os.path.dirname(os.path.abspath(filepath)), exist_ok=True)
+    cfg = {"format": FORMAT, "class_name": model.kind, "image_shape": list(model.image_shape),
+           "compute_dtype": str(_dtype()).replace("torch.", "")}
+    weights, opt = {}, {}
+    if isinstance(model, GanModel):
+        cfg["arch"] = model.g_model.arch
+        weights.update({"g/" + k: v for k, v in model.g_model.get_weights_dict().items()})
+        weights.update({"d/" + k: v for k, v in model.d_model.get_weights_dict().items()})
+        if include_optimizer:
+            opt.update(_opt_state(model._trainer.opt_g, "gan_g/"))
+            opt.update(_opt_state(model._trainer.opt_dbn, "gan_dbn/"))
+    else:
+        if isinstance(model, GeneratorModel):
+            cfg["arch"] = model.arch
+        weights.update(model.get_weights_dict())
+        tr = getattr(model, "_trainer", None)
+        if include_optimizer and tr is not None:
+            opt.update(_opt_state(tr.opt, "opt/"))
+    tmp = filepath + ".tmp"
+    with zipfile.ZipFile(tmp, "w", zipfile.ZIP_STORED) as z:
+        z.writestr("config.json", json.dumps(cfg))
+        z.writestr("metadata.json", json.dumps({"writer": "cfd_amd", "format": FORMAT}))
+        z.writestr("model.weights.npz", _npz_bytes(weights))
+        if opt:
+            z.writestr("optimizer.npz", _npz_bytes(opt))
+    os.replace(tmp, filepath)
+
+
+def load_model(filepath, compile=True, custom_objects=None):
+    """keras.models.load_model counterpart for archives written by save_model above."""
+    with zipfile.ZipFile(str(filepath)) as z:
+        names = set(z.namelist())
+        cfg = json.loads(z.read("config.json"))
+        if cfg.get("format") != FORMAT:
+            if "model.weights.h5" in names:
+                raise NotImplementedError("this is a real Keras HDF5 archive; reading it needs h5py, which is not "
+                                          "installed here (SURVEY.md §8(b))")
+            raise ValueError(f"unknown archive format in {filepath}")
+        w = dict(np.load(io.BytesIO(z.read("model.weights.npz")), allow_pickle=False))
+        o = dict(np.load(io.BytesIO(z.read("optimizer.npz")), allow_pickle=False)) if "optimizer.npz" in names else {}
+    shape = tuple(cfg["image_shape"])
+    kind = cfg["class_name"]
+    if kind == "generator":
+        m = GeneratorModel(cfg["arch"], shape)
+        m.set_weights_dict(w)
+    elif kind == "discriminator":
+        m = DiscriminatorModel(shape)
+        m.set_weights_dict(w)
+        if compile and o:
+            _load_opt(m._tr().opt, o, "opt/")
+    elif kind == "cnn":
+        m = CnnModel(shape)
+        m.set_weights_dict(w)
+        if compile and o:
+            _load_opt(m._tr().opt, o, "opt/")
+    elif kind == "gan":
+        g, d = GeneratorModel(cfg["arch"], shape), DiscriminatorModel(shape)
+        g.set_weights_dict({k[2:]: v for k, v in w.items() if k.startswith("g/")})
+        d.set_weights_dict({k[2:]: v for k, v in w.items() if k.startswith("d/")})
+        m = define_gan(g, d, shape)
+        if compile and o:
+            _load_opt(m._trainer.opt_g, o, "gan_g/")
+            _load_opt(m._trainer.opt_dbn, o, "gan_dbn/")
+    else:
+        raise ValueError(f"unknown model class {kind}")
+    return m
+
+
+def link_gan(gan_model: GanModel, g_model: GeneratorModel, d_model: DiscriminatorModel) -> GanModel:
+    """After loading three separate archives (U/train.py:214-216) the composite must train the SAME G and D
+    objects the script keeps using; Keras restores that sharing only inside one process graph, so the entry
+    scripts call this to re-tie them (the composite's optimizer state is kept)."""
+    tr_old = gan_model._trainer
+    new = GanModel(g_model, d_model, gan_model.image_shape)
+    for a, b in ((new._trainer.opt_g, tr_old.opt_g), (new._trainer.opt_dbn, tr_old.opt_dbn)):
+        a.m.copy_(b.m)
+        a.v.copy_(b.v)
+        a.t = b.t
+    return new

@@ -132,7 +132,7 @@ def conv_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     check(lib.cfd_conv_forward(C.byref(d), xp, _ptr(w), _ptr(bias), yp, _ptr(ws), _stream()), "cfd_conv_forward")
     if _timer is not None:
         e1.record()
-        taps = {CONV_K4S2: 16, CONV_K4S1: 16, CONV_K3S1: 9, CONVT_K4S2: 4, DENSE: 1}[kind]
+        taps = {CONV_K4S2: 16, CONV_K4S1: 16, CONV_K3S1: 9, CONVT_K4S2: 4, DENSE: 1, 5: 16}[kind]
         opix = out.numel() // cout
         _timer.records.append((kind, 2.0 * opix * cout * taps * cin, e0, e1))
     return out

@@ -104,7 +104,6 @@ class DiscriminatorTrainer:
         self.dp.reduce_async(P.grad[self.opt.lo:self.opt.hi])
         self.dp.wait()
         self.opt.step(self.dp.grad_scale)
-        P.refresh_transposed_subset = None
         if self.train_convs:
             P.refresh_transposed()
         d.update_moving(B)

@@ -1,0 +1,85 @@
+"""The drop-in boundary end to end on the GPU: preprocess CLI -> train script (+ resume) -> evaluation,
+through the same names, flags and files the reference's scripts use."""
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_processed_folder(tmp, n_cases):
+    """raw OpenFOAM-like tables -> processed 64x512 CSVs via the preprocess module (GPU resample)"""
+    sys.path.insert(0, ROOT)
+    import pixels_coords_testing as pct
+    from cfd_amd import synthetic
+    folder = tmp / "cases" / "processed"
+    folder.mkdir(parents=True)
+    for s in range(n_cases):
+        arr = synthetic.scattered_case(s, jitter=0.2)
+        pd.DataFrame(arr, columns=["x", "y", "z", "p", "Umean"]).to_csv(folder / f"case_{s:03d}.csv", index=False)
+    pct.height, pct.width = 64, 512
+    pct.process_all_csvs_with_pixel_coordinates(folder)
+    df = pd.read_csv(folder / "case_000.csv")
+    assert list(df.columns) == pct.OUT_COLUMNS and len(df) == 64 * 512
+    return str(folder) + "/"
+
+
+def test_models_namespace_matches_reference():
+    sys.path.insert(0, os.path.join(ROOT, "U"))
+    import importlib
+    for pkg, names in (("U", ["define_generator", "define_discriminator", "define_gan", "save_model", "load_model",
+                              "MC_mse", "MC_mae", "MC_huber_loss"]),):
+        sys.modules.pop("models", None)
+        sys.path.insert(0, os.path.join(ROOT, pkg))
+        m = importlib.import_module("models")
+        for n in names:
+            assert hasattr(m, n), n
+        sys.path.pop(0)
+        sys.modules.pop("models", None)
+
+
+@pytest.mark.parametrize("field", ["U", "DeltaP"])
+def test_train_resume_evaluate(field, tmp_path, monkeypatch):
+    from cfd_amd import cli, keras_api as K
+    folder = make_processed_folder(tmp_path, 20)
+    monkeypatch.chdir(tmp_path)
+    hist = cli.train(field, ["-n", "1", "-t", folder])
+    out = tmp_path / field / os.path.basename(os.path.normpath(cli.FIELDS[field]["default_dir"]))
+    assert (out / "steps.txt").read_text() == "18"            # 20 cases -> 18 train / 2 valid, batch 1
+    assert len(np.loadtxt(out / "train_indices.txt")) == 18 and len(np.loadtxt(out / "valid_indices.txt")) == 2
+    assert (out / "model_ckpt" / "model_G.keras").exists()
+    if field == "U":
+        assert (out / "model_ckpt" / "model_D.keras").exists() and (out / "model_ckpt" / "model_GAN.keras").exists()
+        assert (out / "model_eval.keras").exists()
+    assert len(hist["g"]) == 1 and np.isfinite(hist["g"][0]) and np.isfinite(hist["val"][0])
+    # resume from the checkpoint: continues at the epoch boundary, optimizer state restored
+    hist2 = cli.train(field, ["-c", "true", "-n", "2", "-t", folder])
+    assert (out / "steps.txt").read_text() == "36" and len(hist2["g"]) == 1
+    # weights survive save -> load bit for bit
+    g = K.load_model(str(out / "model_ckpt" / "model_G.keras"), compile=False)
+    w = g.get_weights_dict()
+    K.save_model(g, str(tmp_path / "again.keras"))
+    w2 = K.load_model(str(tmp_path / "again.keras")).get_weights_dict()
+    assert all(np.array_equal(w[k], w2[k]) for k in w)
+    rows, mean_err = cli.evaluate(field, folder, model=g, out_dir=str(tmp_path / "eval"))
+    assert len(rows) == 20 - int(0.9 * 20 + 1) and np.isfinite(mean_err)
+    assert any(p.suffix == ".csv" for p in (tmp_path / "eval").iterdir())
+
+
+def test_keras_surface_shapes():
+    from cfd_amd import keras_api as K
+    d = K.define_discriminator((64, 512, 1))
+    g = K.define_generator_P((64, 512, 1))
+    gan = K.define_gan(g, d, (64, 512, 1))
+    assert d.output_shape[1] == 4                                     # U/train.py:41
+    assert all(isinstance(l, K.BatchNormalization) or not l.trainable for l in d.layers)
+    x = np.random.default_rng(0).standard_normal((2, 64, 512, 1)).astype("float32")
+    y = g.predict([x])
+    assert y.shape == (2, 64, 512, 1) and y.dtype == np.float32
+    out = gan.train_on_batch([x], [np.ones((2, 4, 32, 1)), np.clip(y, 0, 1)])
+    assert len(out) == 3 and abs(out[0] - (out[1] + 100 * out[2])) < 1e-3 * max(1, abs(out[0]))
+    assert g.count_params() == 103_314_177 and d.count_params() == 27_821_953
