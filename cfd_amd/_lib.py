@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcfd_amd.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 CONV_K4S2, CONV_K4S1, CONV_K3S1, CONVT_K4S2, DENSE, CONV_K4S1_BWD = 0, 1, 2, 3, 4, 5
+TUNE_IGEMM256, TUNE_IGEMM256_PD = 0, 1
 
 
 class ConvDesc(C.Structure):
@@ -33,6 +34,7 @@ _vp, _i, _f, _d, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
 SIGNATURES = {
     "cfd_version": (_i, []),
     "cfd_last_error": (C.c_char_p, []),
+    "cfd_set_tuning": (_i, [_i, _i]),
     "cfd_conv_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
     "cfd_conv_suggest_split_k": (_i, [C.POINTER(ConvDesc)]),
     "cfd_conv_forward": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),

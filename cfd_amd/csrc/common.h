@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/cfd_amd.h"
 
@@ -11,6 +12,7 @@ namespace cfd {
 
 // ---- error reporting ---------------------------------------------------------------
 char *last_error_buf();  // thread-local, 512 bytes (api.hip)
+int tuning(int key);     // cfd_set_tuning value, -1 = heuristic (api.hip)
 
 #define CFD_FAIL(code, ...)                                   \
   do {                                                        \

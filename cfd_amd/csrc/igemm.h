@@ -1,0 +1,56 @@
+// Shared between the implicit-GEMM kernels (igemm.hip: 128x128 tile, bf16 + f32; igemm256.hip: 256x256
+// ping-pong tile, bf16).
+#pragma once
+#include "common.h"
+
+namespace cfd {
+
+struct IgemmParams {
+  const char *x;
+  const char *w;
+  const float *bias;
+  char *y;
+  float *ws;
+  int B, Hi, Wi, Cin, Cout, ldx, ldy;
+  int Hq, Wq, M;       // class grid and rows per class
+  int Ho, Wo;          // output grid
+  int Kw;              // weight row length (all taps * Cin)
+  int ntaps;           // taps per class
+  int kind, act, out_bf16;
+  float slope;
+  int mtiles, ntiles, nclass, split_k;
+  int cpt;             // K tiles per tap = Cin / BKE
+  int nblocks;
+};
+
+// tap t of a class -> input-pixel offset (dy,dx) relative to the class-grid pixel * stride, and the
+// weight tap index; uniform (scalar) arithmetic
+__device__ __forceinline__ void tap_geom(int kind, int ph, int pw, int t, int &dy, int &dx, int &wtap) {
+  if (kind == CFD_CONVT_K4S2) {
+    const int kh = (1 - ph) + 2 * (t >> 1), kw = (1 - pw) + 2 * (t & 1);
+    dy = (ph + 1 - kh) / 2;
+    dx = (pw + 1 - kw) / 2;
+    wtap = kh * 4 + kw;
+  } else if (kind == CFD_CONV_K3S1) {
+    const int kh = t / 3, kw = t - kh * 3;
+    dy = kh - 1; dx = kw - 1; wtap = t;
+  } else if (kind == CFD_DENSE) {
+    dy = 0; dx = 0; wtap = 0;
+  } else if (kind == CFD_CONV_K4S1_BWD) {
+    dy = (t >> 2) - 2; dx = (t & 3) - 2; wtap = t;   // pad 2 before / 1 after: data gradient of the k4 s1 'same' conv
+  } else {
+    dy = (t >> 2) - 1; dx = (t & 3) - 1; wtap = t;
+  }
+}
+
+__device__ __forceinline__ void glds16(const char *gsrc, char *lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                   (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+
+// igemm256.hip
+bool igemm256_eligible(const IgemmParams &p, int dtype);
+int igemm256_launch(const IgemmParams &p, hipStream_t st);
+int igemm256_block_count(const IgemmParams &p);
+
+}  // namespace cfd

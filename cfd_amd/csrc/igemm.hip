@@ -22,26 +22,10 @@
 // with (row & 7) on the per-lane SOURCE address and on the fragment read.  Out-of-image taps
 // and rows past M/N read a 16-B zero page, so padding costs no branches in the K loop.
 #include "common.h"
+#include "igemm.h"
 
 namespace cfd {
 
-struct IgemmParams {
-  const char *x;
-  const char *w;
-  const float *bias;
-  char *y;
-  float *ws;
-  int B, Hi, Wi, Cin, Cout, ldx, ldy;
-  int Hq, Wq, M;       // class grid and rows per class
-  int Ho, Wo;          // output grid
-  int Kw;              // weight row length (all taps * Cin)
-  int ntaps;           // taps per class
-  int kind, act, out_bf16;
-  float slope;
-  int mtiles, ntiles, nclass, split_k;
-  int cpt;             // K tiles per tap = Cin / BKE
-  int nblocks;
-};
 
 __device__ __attribute__((aligned(16))) const unsigned int g_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -52,10 +36,6 @@ template <> struct Elem<float> { static constexpr int EPC = 4; static constexpr 
 constexpr int TILE_BYTES = 128 * 128;      // one operand tile: 128 rows x 128 B
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;
 
-__device__ __forceinline__ void glds16(const char *gsrc, char *lds_dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                   (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
-}
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
@@ -114,21 +94,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const int t = kt / p.cpt;
     const int ci0 = (kt - t * p.cpt) * BKE;
     int dy, dx, wtap;
-    if (p.kind == CFD_CONVT_K4S2) {
-      const int kh = (1 - ph) + 2 * (t >> 1), kw = (1 - pw) + 2 * (t & 1);
-      dy = (ph + 1 - kh) / 2;
-      dx = (pw + 1 - kw) / 2;
-      wtap = kh * 4 + kw;
-    } else if (p.kind == CFD_CONV_K3S1) {
-      const int kh = t / 3, kw = t - kh * 3;
-      dy = kh - 1; dx = kw - 1; wtap = t;
-    } else if (p.kind == CFD_DENSE) {
-      dy = 0; dx = 0; wtap = 0;
-    } else if (p.kind == CFD_CONV_K4S1_BWD) {
-      dy = (t >> 2) - 2; dx = (t & 3) - 2; wtap = t;   // pad 2 before / 1 after: data gradient of the k4 s1 'same' conv
-    } else {
-      dy = (t >> 2) - 1; dx = (t & 3) - 1; wtap = t;
-    }
+    tap_geom(p.kind, ph, pw, t, dy, dx, wtap);
     char *wdst = lds + buf * STAGE_BYTES + wave * 1024;
     char *xdst = wdst + TILE_BYTES;
     const int64_t woff = ((int64_t)wtap * p.Cin + ci0) * ES;
@@ -337,14 +303,30 @@ extern "C" int64_t cfd_conv_workspace_bytes(const cfd_conv_desc *d) {
   return (int64_t)p.split_k * p.B * p.Ho * p.Wo * p.Cout * 4;
 }
 
+// kernel choice: the 256x256 ping-pong kernel (igemm256.hip) for large bf16 layers, else the 128x128 kernel.
+// cfd_set_tuning(CFD_TUNE_IGEMM256, 0 | 1) overrides the heuristic (tuning / A-B runs).
+static bool use_igemm256(const IgemmParams &p, int dtype) {
+  if (!igemm256_eligible(p, dtype)) return false;
+  const int mode = tuning(CFD_TUNE_IGEMM256);
+  if (mode >= 0) return mode != 0;
+  const int blocks = cdiv(p.M, 256) * (p.Cout / 256) * p.nclass;
+  return blocks >= 96;
+}
+
 extern "C" int cfd_conv_suggest_split_k(const cfd_conv_desc *d) {
   cfd_conv_desc t = *d;
   t.split_k = 1;
   IgemmParams p;
   if (fill_params(&t, p) != CFD_OK) return 1;
-  const int blocks = p.mtiles * p.ntiles * p.nclass;
   const int ktiles = p.ntaps * p.cpt;
   int s = 1;
+  if (use_igemm256(p, d->dtype)) {
+    // one 512-thread block per CU: fill ~256 blocks, keep >= 8 K tiles per slice
+    const int blocks = cdiv(p.M, 256) * (p.Cout / 256) * p.nclass;
+    while (blocks * s * 2 <= 256 && ktiles / (s * 2) >= 8) s *= 2;
+    return s;
+  }
+  const int blocks = p.mtiles * p.ntiles * p.nclass;
   // fill ~2 blocks per CU (512) but keep >= 8 K tiles per slice
   while (blocks * s * 2 <= 512 && ktiles / (s * 2) >= 8) s *= 2;
   return s;
@@ -360,13 +342,17 @@ extern "C" int cfd_conv_forward(const cfd_conv_desc *d, const void *x, const voi
   p.x = (const char *)x; p.w = (const char *)w; p.bias = bias; p.y = (char *)y; p.ws = (float *)workspace;
   hipStream_t st = (hipStream_t)stream;
   const size_t shmem = 2 * STAGE_BYTES;
-  if (d->dtype == CFD_BF16) {
+  if (use_igemm256(p, d->dtype)) {
+    rc = igemm256_launch(p, st);
+    if (rc != CFD_OK) return rc;
+  } else if (d->dtype == CFD_BF16) {
     static bool attr_done = false;
     if (!attr_done) {
       CFD_HIP(hipFuncSetAttribute((const void *)igemm_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
       attr_done = true;
     }
     hipLaunchKernelGGL(igemm_kernel<bf16>, dim3(p.nblocks), dim3(256), shmem, st, p);
+    CFD_LAUNCH_CHECK();
   } else {
     static bool attr_done = false;
     if (!attr_done) {
@@ -374,8 +360,8 @@ extern "C" int cfd_conv_forward(const cfd_conv_desc *d, const void *x, const voi
       attr_done = true;
     }
     hipLaunchKernelGGL(igemm_kernel<float>, dim3(p.nblocks), dim3(256), shmem, st, p);
+    CFD_LAUNCH_CHECK();
   }
-  CFD_LAUNCH_CHECK();
   if (p.split_k > 1) {
     const int64_t npix = (int64_t)p.B * p.Ho * p.Wo;
     const int64_t total = npix * p.Cout;

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, CONV_K3S1, CONV_K4S1, CONV_K4S2, CONVT_K4S2,
-                   DENSE, F32, ConvDesc, check)
+                   DENSE, F32, TUNE_IGEMM256, TUNE_IGEMM256_PD, ConvDesc, check)
 
 LEAKY_SLOPE = 0.2
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
@@ -57,6 +57,11 @@ def conv_out_shape(kind: int, B: int, Hi: int, Wi: int, cout: int):
     if kind == CONVT_K4S2:
         return (B, Hi * 2, Wi * 2, cout)
     return (B, Hi, Wi, cout)
+
+
+def set_tuning(key: int, value: int) -> None:
+    """cfd_set_tuning: A/B switches of the library (see include/cfd_amd.h); -1 restores the heuristic."""
+    check(_lib.load().cfd_set_tuning(int(key), int(value)), "cfd_set_tuning")
 
 
 _ws_cache = {}

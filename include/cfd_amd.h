@@ -35,6 +35,12 @@ typedef enum { CFD_ACT_NONE = 0, CFD_ACT_LEAKY = 1, CFD_ACT_RELU = 2, CFD_ACT_SI
 /* library */
 int cfd_version(void);
 const char *cfd_last_error(void);
+/* Tuning / A-B switches (no counterpart in the reference; process-wide, not thread-safe against running calls).
+ *   CFD_TUNE_IGEMM256     -1 heuristic (default) | 0 never | 1 whenever eligible: use the 256x256 ping-pong
+ *                         bf16 implicit-GEMM kernel instead of the 128x128 one
+ *   CFD_TUNE_IGEMM256_PD  prefetch distance of that kernel in half tiles: 5 (default) or 6 */
+typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_COUNT = 2 } cfd_tuning_key;
+int cfd_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------
  * Convolutions as implicit GEMM on MFMA.

@@ -64,8 +64,13 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--modes", default="fwd,dgrad,wgrad")
+    ap.add_argument("--igemm256", type=int, default=-1, help="-1 heuristic, 0 never, 1 whenever eligible")
+    ap.add_argument("--pd", type=int, default=-1)
+    ap.add_argument("--only", default="", help="comma list of layer names, e.g. e2,d4")
     args = ap.parse_args()
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    ops.set_tuning(ops.TUNE_IGEMM256, args.igemm256)
+    ops.set_tuning(ops.TUNE_IGEMM256_PD, args.pd)
     B = args.batch
     nets = ["U", "P", "D", "DeltaP"] if args.net == "all" else [args.net]
     modes = args.modes.split(",")
@@ -73,6 +78,8 @@ def main():
     for net in nets:
         layers = gen_layers(net) if net in ("U", "P") else (disc_layers() if net == "D" else cnn_layers())
         for name, kind, h, w, cin, cout in layers:
+            if args.only and name not in args.only.split(","):
+                continue
             g = torch.Generator(device="cuda").manual_seed(1)
             if kind == DENSE:
                 x = (torch.rand((B, cin), device="cuda", generator=g) - 0.5).to(tdt)

@@ -75,6 +75,60 @@ def test_conv_forward(kind, B, H, W, cin, cout, dtype):
     assert relerr(y.cpu(), ref) <= 1e-4
 
 
+@pytest.mark.parametrize("pd", [5, 6])
+@pytest.mark.parametrize("kind,B,H,W,cin,cout,split_k", [
+    ("k4s2", 2, 16, 64, 64, 256, 1),      # two full 256-row tiles, one tap-major K sweep
+    ("k4s2", 3, 12, 20, 128, 512, 1),     # ragged last m tile (M = 180), two n tiles
+    ("k4s2", 1, 2, 16, 128, 256, 4),      # M = 8 << tile, split-K slabs
+    ("k4s1", 2, 4, 32, 64, 256, 1),       # asymmetric 'same' padding
+    ("k3s1", 2, 16, 32, 64, 256, 1),      # 9 taps
+    ("convT", 2, 8, 24, 128, 256, 1),     # four parity classes, ragged tiles (M = 384)
+    ("convT", 1, 1, 8, 64, 256, 2),       # 1x8 input, split-K
+    ("dense", 5, 1, 1, 1024, 256, 1),     # dense, M = 5
+])
+def test_conv_forward_igemm256(kind, B, H, W, cin, cout, split_k, pd):
+    """the 256x256 ping-pong bf16 kernel (igemm256.hip), forced on, against the oracle; bias + LeakyReLU fused,
+    bf16 output written into a channel slice of a wider buffer"""
+    from cfd_amd import ops
+    dev, dtype = "cuda", torch.bfloat16
+    x = q(rnd((B, H, W, cin), 1), dtype)
+    bias = rnd((cout,), 3, 0.1)
+    ops.set_tuning(ops.TUNE_IGEMM256, 1)
+    ops.set_tuning(ops.TUNE_IGEMM256_PD, pd)
+    try:
+        if kind == "dense":
+            wk = q(rnd((cin, cout), 2, 0.05), dtype)
+            ref = x.reshape(B, cin) @ wk + bias
+            wp = ops.pack_dense_weight(wk.to(dev), dtype)
+            xin, code, oshape = x.reshape(B, cin), ops.DENSE, (B, cout)
+        elif kind == "convT":
+            wk = q(rnd((4, 4, cout, cin), 2, 0.05), dtype)
+            ref = O.conv2d_transpose_same(x, wk, bias)
+            wp = ops.pack_convT_weight(wk.to(dev), dtype)
+            xin, code, oshape = x, ops.CONVT_K4S2, tuple(ref.shape)
+        else:
+            k, s, code = {"k4s2": (4, 2, ops.CONV_K4S2), "k4s1": (4, 1, ops.CONV_K4S1),
+                          "k3s1": (3, 1, ops.CONV_K3S1)}[kind]
+            wk = q(rnd((k, k, cin, cout), 2, 0.05), dtype)
+            ref = O.conv2d_same(x, wk, bias, s)
+            wp = ops.pack_conv_weight(wk.to(dev), dtype)
+            xin, oshape = x, tuple(ref.shape)
+        # fp32 output, no activation: only the accumulation order differs from the oracle
+        y = ops.conv_forward(xin.to(dev).to(dtype), wp, bias.to(dev), code, cout, out_dtype=torch.float32,
+                             split_k=split_k)
+        # bf16 output + LeakyReLU into a channel slice
+        buf = torch.zeros(oshape[:-1] + (cout + 64,), dtype=dtype, device=dev)
+        ops.conv_forward(xin.to(dev).to(dtype), wp, bias.to(dev), code, cout, act=ops.ACT_LEAKY, out=buf[..., 64:],
+                         split_k=split_k)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning(ops.TUNE_IGEMM256, -1)
+        ops.set_tuning(ops.TUNE_IGEMM256_PD, -1)
+    assert relerr(y.cpu(), ref) <= 1e-4
+    assert relerr(buf[..., 64:].float().cpu(), O.leaky(ref)) <= TOL[dtype]
+    assert float(buf[..., :64].float().abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_forward_splitk_act_slice(dtype):
     """split-K path, fused LeakyReLU, bf16/f32 output written into a channel slice of a wider buffer."""
