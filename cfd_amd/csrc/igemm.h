@@ -25,7 +25,7 @@ struct IgemmParams {
 
 // tap t of a class -> input-pixel offset (dy,dx) relative to the class-grid pixel * stride, and the
 // weight tap index; uniform (scalar) arithmetic
-__device__ __forceinline__ void tap_geom(int kind, int ph, int pw, int t, int &dy, int &dx, int &wtap) {
+__host__ __device__ __forceinline__ void tap_geom(int kind, int ph, int pw, int t, int &dy, int &dx, int &wtap) {
   if (kind == CFD_CONVT_K4S2) {
     const int kh = (1 - ph) + 2 * (t >> 1), kw = (1 - pw) + 2 * (t & 1);
     dy = (ph + 1 - kh) / 2;

@@ -305,12 +305,25 @@ extern "C" int64_t cfd_conv_workspace_bytes(const cfd_conv_desc *d) {
 
 // kernel choice: the 256x256 ping-pong kernel (igemm256.hip) for large bf16 layers, else the 128x128 kernel.
 // cfd_set_tuning(CFD_TUNE_IGEMM256, 0 | 1) overrides the heuristic (tuning / A-B runs).
+// split-K choice for the 256x256 kernel: one 512-thread block per CU, so fill ~256 blocks, and keep the K loop
+// of a slice long enough (>= 8 K tiles) to amortise the pipeline prologue
+static int split_k_256(const IgemmParams &p) {
+  const int blocks = cdiv(p.M, 256) * (p.Cout / 256) * p.nclass;
+  const int ktiles = p.ntaps * p.cpt;
+  int s = 1;
+  while (blocks * s * 2 <= 256 && ktiles / (s * 2) >= 8) s *= 2;
+  return s;
+}
+
 static bool use_igemm256(const IgemmParams &p, int dtype) {
   if (!igemm256_eligible(p, dtype)) return false;
   const int mode = tuning(CFD_TUNE_IGEMM256);
   if (mode >= 0) return mode != 0;
+  // measured (scripts/layer_bench.py, B = 16..64): the ping-pong kernel wins once a slice runs >= 32 K tiles
+  // and the launch fills at least half the chip; below that the 128x128 kernel's 2 blocks/CU hide more
   const int blocks = cdiv(p.M, 256) * (p.Cout / 256) * p.nclass;
-  return blocks >= 96;
+  const int s = split_k_256(p);
+  return blocks * s >= 128 && (p.ntaps * p.cpt) / s >= 32;
 }
 
 extern "C" int cfd_conv_suggest_split_k(const cfd_conv_desc *d) {
@@ -318,14 +331,9 @@ extern "C" int cfd_conv_suggest_split_k(const cfd_conv_desc *d) {
   t.split_k = 1;
   IgemmParams p;
   if (fill_params(&t, p) != CFD_OK) return 1;
+  if (use_igemm256(p, d->dtype)) return split_k_256(p);
   const int ktiles = p.ntaps * p.cpt;
   int s = 1;
-  if (use_igemm256(p, d->dtype)) {
-    // one 512-thread block per CU: fill ~256 blocks, keep >= 8 K tiles per slice
-    const int blocks = cdiv(p.M, 256) * (p.Cout / 256) * p.nclass;
-    while (blocks * s * 2 <= 256 && ktiles / (s * 2) >= 8) s *= 2;
-    return s;
-  }
   const int blocks = p.mtiles * p.ntiles * p.nclass;
   // fill ~2 blocks per CU (512) but keep >= 8 K tiles per slice
   while (blocks * s * 2 <= 512 && ktiles / (s * 2) >= 8) s *= 2;

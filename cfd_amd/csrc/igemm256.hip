@@ -14,19 +14,32 @@
 //     issue of half tile H(q+PD)) -> barrier -> 16 MFMAs of quadrant p -> barrier.
 //       p0: read A0,B0 -> A0xB0     p1: read B1 -> A0xB1     p2: read A1 -> A1xB1     p3: (no read) A1xB0
 //   * waves 4..7 run one barrier behind waves 0..3, so on every SIMD one wave is in its MFMA cluster
-//     while the other is in its memory cluster (the two waves of a SIMD are w and w+4).
+//     while the other is in its memory cluster (the two waves of a SIMD are w and w+4).  A wave issues
+//     at most one instruction per ~4 cycles, so the memory cluster must stay well under 64 instructions
+//     to fit beside a 256-cycle MFMA cluster: addresses are therefore 32-bit buffer offsets
+//     (buffer_load ... lds: per-lane voffset precomputed per tap, K position in the scalar soffset,
+//     out-of-image taps = an out-of-range voffset, which the hardware zero-fills), the per-tap geometry
+//     comes from a host-built table in the kernel arguments, and the K loop is unrolled by two so
+//     stage addresses are immediates.
 //   * LDS-DMA stays in flight across barriers: counted s_waitcnt vmcnt(2*(PD-2)) + raw s_barrier; a half
 //     tile is read one phase after the wait that retires it and restaged >= 2 phases after its last read.
-//     Past the end of the K range the stream issues zero-page loads, so the counts stay uniform.
+//     Past the end of the K range the stream re-issues the last K tile (into slots nobody reads again),
+//     so the counts stay uniform.
 #include "common.h"
 #include "igemm.h"
 
 namespace cfd {
 
-__device__ __attribute__((aligned(16))) const unsigned int g_zero_page256[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-
 constexpr int HT_BYTES = 128 * 128;   // half tile
 constexpr int ST_BYTES = 4 * HT_BYTES;
+constexpr unsigned OOB = 0x80000000u;  // voffset beyond any num_records we accept (< 2^31): reads as zero
+
+struct Igemm256Params {
+  IgemmParams g;
+  unsigned xbytes, wbytes;   // buffer sizes for the range check
+  int tapinfo[4][16];        // per class, per tap: (dy*Wi + dx) pixel offset << 8 | weight tap index
+  short tapdy[4][16], tapdx[4][16];
+};
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -37,9 +50,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
+__device__ __forceinline__ void bload16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char *lds_dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_dst, 16, (int)voff,
+                                           (int)soff, 0, 0);
+}
+
 template <int PD>
-__global__ __launch_bounds__(512, 2) void igemm256_kernel(IgemmParams p) {
+__global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const IgemmParams &p = P.g;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -63,19 +82,23 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(IgemmParams p) {
   const int ktiles = p.ntaps * p.cpt;
   const int kbeg = (int)((int64_t)ktiles * sk / p.split_k);
   const int kend = (int)((int64_t)ktiles * (sk + 1) / p.split_k);
-  const char *zero = (const char *)g_zero_page256;
+  const int nkt = kend - kbeg;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)P.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)P.wbytes, 0x00020000);
 
   // ---- staging geometry: a half tile = 16 wave-instructions of 1 KiB (8 rows x 128 B); wave w issues
   // pieces w and 8 + w.  Lane -> row lane/8 of its piece, physical chunk lane%8, which holds the
   // LOGICAL chunk (lane%8) ^ (lane/8): the swizzle is applied on the source address (LDS image stays lane-linear).
   const int lrow = lane >> 3;
   const int chunk = (lane & 7) ^ lrow;
-  // A side: one per-lane pointer; halves / pieces differ by uniform multiples of Kw
-  const char *wbase = p.w + ((int64_t)(n0 + wave * 8 + lrow) * p.Kw + chunk * 8) * 2;
-  const int64_t wstep64 = (int64_t)64 * p.Kw * 2;   // 64 rows further
+  // A side: byte offset of this lane's chunk in row (n0 + half*128 + piece*64 + wave*8 + lrow), r = half*2 + piece
+  unsigned avoff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    avoff[r] = (unsigned)(((n0 + (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow) * p.Kw + chunk * 8) * 2);
   // B side: four pixel rows per lane, r = half*2 + piece
-  const char *xrow[4];
-  unsigned vmask[4];
+  unsigned rowoff[4], vmask[4], cur[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int m = m0 + (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow;
@@ -85,12 +108,11 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(IgemmParams p) {
     const int rem = mm - b * (p.Hq * p.Wq);
     const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
     const int y0 = qy * S, x0 = qx * S;
-    xrow[r] = p.x + ((int64_t)((b * p.Hi + y0) * p.Wi + x0) * p.ldx + chunk * 8) * 2;
+    rowoff[r] = (unsigned)((((b * p.Hi + y0) * p.Wi + x0) * p.ldx + chunk * 8) * 2);
     unsigned msk = 0;
 #pragma clang loop vectorize(disable) unroll(disable)
     for (int t = 0; t < p.ntaps; ++t) {
-      int dy, dx, wt;
-      tap_geom(p.kind, ph, pw, t, dy, dx, wt);
+      const int dy = P.tapdy[cls][t], dx = P.tapdx[cls][t];
       const bool ok = mv && (unsigned)(y0 + dy) < (unsigned)p.Hi && (unsigned)(x0 + dx) < (unsigned)p.Wi;
       msk |= (ok ? 1u : 0u) << t;
     }
@@ -98,50 +120,49 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(IgemmParams p) {
   }
 
   // ---- issue stream state (uniform): the K tile whose half tiles are being issued
-  int iss_kt = kbeg, iss_t = kbeg / p.cpt, iss_c = kbeg - iss_t * p.cpt;
-  int64_t iss_woff = 0, iss_xoff = 0;
-  bool iss_ok = false;
-  auto iss_update = [&]() {
-    iss_ok = iss_kt < kend;
-    int dy, dx, wt;
-    tap_geom(p.kind, ph, pw, iss_ok ? iss_t : 0, dy, dx, wt);
-    const int ci0 = iss_c * 64;
-    iss_woff = ((int64_t)wt * p.Cin + ci0) * 2;
-    iss_xoff = ((int64_t)(dy * p.Wi + dx) * p.ldx + ci0) * 2;
+  int iss_left = nkt;                       // K tiles not yet fully issued (incl. the current one)
+  int iss_t = kbeg / p.cpt, iss_c = kbeg - iss_t * p.cpt;
+  unsigned s_a = 0, s_b = 0;                // scalar byte offsets: A = (wtap*Cin + c*64)*2, B = c*128
+  auto tap_switch = [&]() {
+    const int info = P.tapinfo[cls][iss_t];
+    s_a = (unsigned)(((info & 255) * p.Cin + iss_c * 64) * 2);
+    s_b = (unsigned)(iss_c * 128);
+    const int tapx = (info >> 8) * p.ldx * 2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cur[r] = ((vmask[r] >> iss_t) & 1u) ? rowoff[r] + (unsigned)tapx : OOB;
   };
   auto iss_advance = [&]() {
-    ++iss_kt;
-    if (++iss_c == p.cpt) { iss_c = 0; ++iss_t; }
-    iss_update();
+    if (iss_left > 1) {
+      --iss_left;
+      s_a += 128; s_b += 128;
+      if (++iss_c == p.cpt) { iss_c = 0; ++iss_t; tap_switch(); }
+    }
   };
-  iss_update();
+  tap_switch();
 
-  auto issue = [&](int slot, int stage) {   // slot is a compile-time constant at every call site
-    char *dst = lds + stage * ST_BYTES + slot * HT_BYTES + wave * 1024;
-    if (slot == 0 || slot == 3) {
-      const int64_t hoff = (slot == 3 ? 2 * wstep64 : 0) + iss_woff;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const char *src = iss_ok ? wbase + hoff + i * wstep64 : zero;
-        glds16(src, dst + i * 8192);
-      }
+  char *const ldsw = lds + wave * 1024;
+  auto issue = [&](int slot, int stage) {   // compile-time constants at every call site
+    char *dst = ldsw + stage * ST_BYTES + slot * HT_BYTES;
+    if (slot == 0) {
+      bload16(wrs, avoff[0], s_a, dst); bload16(wrs, avoff[1], s_a, dst + 8192);
+    } else if (slot == 3) {
+      bload16(wrs, avoff[2], s_a, dst); bload16(wrs, avoff[3], s_a, dst + 8192);
+    } else if (slot == 1) {
+      bload16(xrs, cur[0], s_b, dst); bload16(xrs, cur[1], s_b, dst + 8192);
     } else {
-      const int h = slot - 1;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = h * 2 + i;
-        const bool ok = iss_ok && ((vmask[r] >> iss_t) & 1u);
-        const char *src = ok ? xrow[r] + iss_xoff : zero;
-        glds16(src, dst + i * 8192);
-      }
+      bload16(xrs, cur[2], s_b, dst); bload16(xrs, cur[3], s_b, dst + 8192);
     }
   };
 
   // ---- fragment read offsets (bytes inside a half tile); k-step 1 is the same address ^ 64
   const int fr = lane & 15, fq = lane >> 4;
   const int laneoff = fr * 128 + ((fq ^ (fr & 7)) << 4);
-  const int aoff = wr * 64 * 128 + laneoff;   // + i*2048
-  const int boff = wc * 32 * 128 + laneoff;   // + j*2048
+  const char *ard[2], *brd[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    ard[s] = lds + ((wr * 64 * 128 + laneoff) ^ (s << 6));
+    brd[s] = lds + ((wc * 32 * 128 + laneoff) ^ (s << 6));
+  }
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -160,15 +181,12 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(IgemmParams p) {
   if (wr == 1) __builtin_amdgcn_s_barrier();   // second group runs one barrier behind
 
   bf16x8 a[4][2], b0[2][2], b1[2][2];
-  const int nkt = kend - kbeg;
-  for (int k = 0; k < nkt; ++k) {
-    const char *sb = lds + (k & 1) * ST_BYTES;
 
-#define CFD_PHASE(P, READS, MFMAS)                                                     \
+#define CFD_PHASE(ST, PH, READS, MFMAS)                                                \
     {                                                                                  \
       READS                                                                            \
-      issue((P + PD) & 3, (k + ((P + PD) >> 2)) & 1);                                  \
-      if (((P + PD) & 3) == 3) iss_advance();                                          \
+      issue((PH + PD) & 3, (ST + ((PH + PD) >> 2)) & 1);                               \
+      if (((PH + PD) & 3) == 3) iss_advance();                                         \
       wait_vmcnt<2 * (PD - 2)>();                                                      \
       __builtin_amdgcn_s_barrier();                                                    \
       __builtin_amdgcn_sched_barrier(0);                                               \
@@ -178,54 +196,44 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(IgemmParams p) {
       __builtin_amdgcn_sched_barrier(0);                                               \
       __builtin_amdgcn_s_barrier();                                                    \
     }
+#define CFD_MFMA(AI, BJ, BREG)                                                         \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                \
+            acc[AI + i][BJ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], BREG[j][s], acc[AI + i][BJ + j], 0, 0, 0);
+#define CFD_KTILE(ST)                                                                  \
+    CFD_PHASE(ST, 0,                                                                   \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                  \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                  \
+          b0[j][s] = *(const bf16x8 *)(brd[s] + ST * ST_BYTES + 1 * HT_BYTES + j * 2048); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
+          a[i][s] = *(const bf16x8 *)(ard[s] + ST * ST_BYTES + 0 * HT_BYTES + i * 2048); \
+      },                                                                               \
+      CFD_MFMA(0, 0, b0))                                                              \
+    CFD_PHASE(ST, 1,                                                                   \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                  \
+          b1[j][s] = *(const bf16x8 *)(brd[s] + ST * ST_BYTES + 2 * HT_BYTES + j * 2048); \
+      ,                                                                                \
+      CFD_MFMA(0, 2, b1))                                                              \
+    CFD_PHASE(ST, 2,                                                                   \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
+          a[i][s] = *(const bf16x8 *)(ard[s] + ST * ST_BYTES + 3 * HT_BYTES + i * 2048); \
+      ,                                                                                \
+      CFD_MFMA(4, 2, b1))                                                              \
+    CFD_PHASE(ST, 3, , CFD_MFMA(4, 0, b0))
 
-    // phase 0: A0 x B0
-    CFD_PHASE(0,
-      _Pragma("unroll") for (int s = 0; s < 2; ++s) {
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)
-          b0[j][s] = *(const bf16x8 *)(sb + 1 * HT_BYTES + j * 2048 + (boff ^ (s << 6)));
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)
-          a[i][s] = *(const bf16x8 *)(sb + 0 * HT_BYTES + i * 2048 + (aoff ^ (s << 6)));
-      },
-      _Pragma("unroll") for (int s = 0; s < 2; ++s)
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)
-          _Pragma("unroll") for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b0[j][s], acc[i][j], 0, 0, 0);
-    )
-    // phase 1: A0 x B1
-    CFD_PHASE(1,
-      _Pragma("unroll") for (int s = 0; s < 2; ++s)
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)
-          b1[j][s] = *(const bf16x8 *)(sb + 2 * HT_BYTES + j * 2048 + (boff ^ (s << 6)));
-      ,
-      _Pragma("unroll") for (int s = 0; s < 2; ++s)
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)
-          _Pragma("unroll") for (int j = 0; j < 2; ++j)
-            acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b1[j][s], acc[i][2 + j], 0, 0, 0);
-    )
-    // phase 2: A1 x B1
-    CFD_PHASE(2,
-      _Pragma("unroll") for (int s = 0; s < 2; ++s)
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)
-          a[i][s] = *(const bf16x8 *)(sb + 3 * HT_BYTES + i * 2048 + (aoff ^ (s << 6)));
-      ,
-      _Pragma("unroll") for (int s = 0; s < 2; ++s)
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)
-          _Pragma("unroll") for (int j = 0; j < 2; ++j)
-            acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b1[j][s], acc[4 + i][2 + j], 0, 0, 0);
-    )
-    // phase 3: A1 x B0 (operands already in registers)
-    CFD_PHASE(3,
-      ,
-      _Pragma("unroll") for (int s = 0; s < 2; ++s)
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)
-          _Pragma("unroll") for (int j = 0; j < 2; ++j)
-            acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b0[j][s], acc[4 + i][j], 0, 0, 0);
-    )
-#undef CFD_PHASE
+  for (int k = 0; k < nkt; k += 2) {
+    CFD_KTILE(0)
+    if (k + 1 >= nkt) break;
+    CFD_KTILE(1)
   }
+#undef CFD_KTILE
+#undef CFD_MFMA
+#undef CFD_PHASE
   if (wr == 0) __builtin_amdgcn_s_barrier();
-  wait_vmcnt<0>();   // the zero-page tail loads must not outlive the workgroup's LDS allocation
+  wait_vmcnt<0>();   // the tail loads must not outlive the workgroup's LDS allocation
 
   // ---- epilogue: lane holds channels n..n+3 (register index) of pixel m
 #pragma unroll
@@ -261,8 +269,12 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(IgemmParams p) {
   }
 }
 
+static int64_t x_bytes(const IgemmParams &p) { return (((int64_t)p.B * p.Hi * p.Wi - 1) * p.ldx + p.Cin) * 2; }
+static int64_t w_bytes(const IgemmParams &p) { return (int64_t)p.Cout * p.Kw * 2; }
+
 bool igemm256_eligible(const IgemmParams &p, int dtype) {
-  return dtype == CFD_BF16 && p.Cout % 256 == 0 && p.Cin % 64 == 0 && p.ntaps <= 16;
+  return dtype == CFD_BF16 && p.Cout % 256 == 0 && p.Cin % 64 == 0 && p.ntaps <= 16 &&
+         x_bytes(p) < (1LL << 31) && w_bytes(p) < (1LL << 31);
 }
 
 int igemm256_block_count(const IgemmParams &p) {
@@ -270,10 +282,23 @@ int igemm256_block_count(const IgemmParams &p) {
 }
 
 int igemm256_launch(const IgemmParams &pin, hipStream_t st) {
-  IgemmParams p = pin;
+  Igemm256Params P;
+  memset(&P, 0, sizeof(P));
+  P.g = pin;
+  IgemmParams &p = P.g;
   p.mtiles = cdiv(p.M, 256);
   p.ntiles = p.Cout / 256;
   p.nblocks = p.mtiles * p.ntiles * p.nclass * p.split_k;
+  P.xbytes = (unsigned)x_bytes(p);
+  P.wbytes = (unsigned)w_bytes(p);
+  for (int cls = 0; cls < p.nclass; ++cls)
+    for (int t = 0; t < p.ntaps; ++t) {
+      int dy, dx, wt;
+      tap_geom(p.kind, cls >> 1, cls & 1, t, dy, dx, wt);
+      P.tapinfo[cls][t] = ((dy * p.Wi + dx) << 8) | wt;
+      P.tapdy[cls][t] = (short)dy;
+      P.tapdx[cls][t] = (short)dx;
+    }
   const size_t shmem = 2 * ST_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
@@ -281,10 +306,10 @@ int igemm256_launch(const IgemmParams &pin, hipStream_t st) {
     CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     attr_done = true;
   }
-  if (tuning(CFD_TUNE_IGEMM256_PD) == 6)
-    hipLaunchKernelGGL(igemm256_kernel<6>, dim3(p.nblocks), dim3(512), shmem, st, p);
+  if (tuning(CFD_TUNE_IGEMM256_PD) == 5)
+    hipLaunchKernelGGL(igemm256_kernel<5>, dim3(p.nblocks), dim3(512), shmem, st, P);
   else
-    hipLaunchKernelGGL(igemm256_kernel<5>, dim3(p.nblocks), dim3(512), shmem, st, p);
+    hipLaunchKernelGGL(igemm256_kernel<6>, dim3(p.nblocks), dim3(512), shmem, st, P);
   CFD_LAUNCH_CHECK();
   return CFD_OK;
 }
