@@ -38,6 +38,8 @@ SIGNATURES = {
     "cfd_conv_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
     "cfd_conv_suggest_split_k": (_i, [C.POINTER(ConvDesc)]),
     "cfd_conv_forward": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cfd_conv_stats_fusable": (_i, [C.POINTER(ConvDesc)]),
+    "cfd_conv_forward_stats": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cfd_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cfd_pack_convT_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cfd_pack_dense_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -45,6 +47,8 @@ SIGNATURES = {
     "cfd_convT_out": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cfd_bn_act": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, C.c_uint64, _i64, _vp, _i, _vp, _i, _i, _i, _i, _f, _i,
                         _i, _f, _i, _vp]),
+    "cfd_bn_apply": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, C.c_uint64, _i64, _vp, _i, _vp, _i, _i, _i,
+                          _i, _f, _i, _i, _f, _i, _vp]),
     "cfd_dropout_mask": (_i, [_vp, _i64, _i, _i, _i, _f, C.c_uint64, _vp]),
     "cfd_maxpool2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cfd_cast_copy": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),

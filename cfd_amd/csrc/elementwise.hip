@@ -180,6 +180,79 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const TI *__restrict__ x, i
   }
 }
 
+
+// BatchNorm apply for conv outputs whose per-sample statistics were accumulated by the conv epilogue
+// (cfd_conv_forward_stats): ONE read of x, fully coalesced (a pixel row of C channels is covered by C/8
+// consecutive threads, 16 B each), normalise + dropout + activation(s), write y (and y2).
+// Block = (sample b, chunk of pixels); thread = fixed 8-channel vector, so scale/shift live in registers.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const TI *__restrict__ x, int ldx, const float *__restrict__ ssum,
+                                                      const float *__restrict__ ssq, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, float *__restrict__ mean_out,
+                                                      float *__restrict__ var_out, const uint8_t *__restrict__ mask,
+                                                      float drop_scale, unsigned drop_thr, uint64_t drop_seed,
+                                                      int64_t sample0, TO *__restrict__ y, int ldy, TO *__restrict__ y2,
+                                                      int ldy2, int HW, int C, float eps, int act, int act2, float slope,
+                                                      int chunks, int pix_per_chunk) {
+  const int CV = C >> 3;          // threads per pixel row (host: CV <= 256 and 256 % CV == 0)
+  const int rpar = 256 / CV;
+  const int cv = (threadIdx.x % CV) * 8, rl = threadIdx.x / CV;
+  const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+  float sc[8], sf[8];
+  {
+    const float inv_n = 1.f / (float)HW;
+    float s1[8], s2[8], g[8], be[8];
+    VecIO<float, 8>::load(ssum + (size_t)b * C + cv, s1);
+    VecIO<float, 8>::load(ssq + (size_t)b * C + cv, s2);
+    VecIO<float, 8>::load(gamma + cv, g);
+    VecIO<float, 8>::load(beta + cv, be);
+    float mean[8], var[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      mean[i] = s1[i] * inv_n;
+      const float v = fmaf(-mean[i], mean[i], s2[i] * inv_n);
+      var[i] = v > 0.f ? v : 0.f;
+      sc[i] = g[i] * rsqrtf(var[i] + eps);
+      sf[i] = be[i] - mean[i] * sc[i];
+    }
+    if (chunk == 0 && rl == 0) {
+      if (mean_out) VecIO<float, 8>::store(mean_out + (size_t)b * C + cv, mean);
+      if (var_out) VecIO<float, 8>::store(var_out + (size_t)b * C + cv, var);
+    }
+  }
+  const int p0 = chunk * pix_per_chunk;
+  const int p1 = p0 + pix_per_chunk < HW ? p0 + pix_per_chunk : HW;
+  const TI *xb = x + (size_t)b * HW * ldx + cv;
+  TO *yb = y + (size_t)b * HW * ldy + cv;
+  TO *y2b = y2 ? y2 + (size_t)b * HW * ldy2 + cv : nullptr;
+  const uint8_t *mb = mask ? mask + (size_t)b * HW * C + cv : nullptr;
+  for (int p = p0 + rl; p < p1; p += rpar) {
+    float f[8];
+    VecIO<TI, 8>::load(xb + (size_t)p * ldx, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = fmaf(f[i], sc[i], sf[i]);
+    if (mb) {
+      const uint8_t *mp = mb + (size_t)p * C;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = mp[i] ? f[i] * drop_scale : 0.f;
+    } else if (drop_thr) {
+      const uint64_t e0 = ((uint64_t)(sample0 + b) * HW + p) * C + cv;   // multiple of 8
+      const uint64_t h = dropout_hash(drop_seed, e0 >> 3);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = (((h >> (8 * i)) & 0xff) >= drop_thr) ? f[i] * drop_scale : 0.f;
+    }
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = apply_act(f[i], act, slope);
+    VecIO<TO, 8>::store(yb + (size_t)p * ldy, o);
+    if (y2b) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = apply_act(f[i], act2, slope);
+      VecIO<TO, 8>::store(y2b + (size_t)p * ldy2, o);
+    }
+  }
+}
+
 template <typename T>
 __global__ void maxpool2_kernel(const T *__restrict__ x, T *__restrict__ y, int B, int Hi, int Wi, int C) {
   typedef typename Vec<T>::type V;
@@ -263,6 +336,37 @@ extern "C" int cfd_bn_act(const void *x, int ldx, int x_dtype, const float *gamm
   else if (dtype == CFD_BF16) BN_LAUNCH(float, bf16, 8);
   else BN_LAUNCH(float, float, 4);
 #undef BN_LAUNCH
+  CFD_LAUNCH_CHECK();
+  return CFD_OK;
+}
+
+extern "C" int cfd_bn_apply(const void *x, int ldx, int x_dtype, const float *stat_sum, const float *stat_sq,
+                            const float *gamma, const float *beta, float *mean, float *var, const uint8_t *drop_mask,
+                            float drop_rate, uint64_t drop_seed, int64_t sample0, void *y, int ldy, void *y2, int ldy2,
+                            int B, int HW, int C, float eps, int act, int act2, float slope, int dtype, void *stream) {
+  CFD_REQUIRE(drop_rate >= 0.f && drop_rate < 1.f, "drop_rate must be in [0,1)");
+  const float drop_scale = 1.f / (1.f - drop_rate);
+  const unsigned drop_thr = (drop_mask || drop_rate == 0.f) ? 0u : drop_threshold(drop_rate);
+  CFD_REQUIRE(x && stat_sum && stat_sq && gamma && beta && y, "NULL pointer");
+  CFD_REQUIRE(dtype == CFD_BF16 || dtype == CFD_F32, "bad dtype");
+  CFD_REQUIRE(x_dtype == CFD_F32 || (x_dtype == CFD_BF16 && dtype == CFD_BF16), "bad x_dtype/dtype combination");
+  CFD_REQUIRE(B > 0 && HW > 0 && C >= 64 && C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0,
+              "bn_apply: C=%d must be 64..2048 with C/8 a divisor of 256", C);
+  CFD_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && (!y2 || ldy2 % 8 == 0), "ldx/ldy must be multiples of 8");
+  // ~16 pixel rows per thread-row keeps >= 2048 blocks in flight on the big layers without shrinking a block's run
+  const int rpar = 256 / (C / 8);
+  int ppc = rpar * 16;
+  if (ppc > HW) ppc = HW;
+  const int chunks = (HW + ppc - 1) / ppc;
+  hipStream_t st = (hipStream_t)stream;
+#define BNA_LAUNCH(TI, TO)                                                                                            \
+  hipLaunchKernelGGL((bn_apply_kernel<TI, TO>), dim3(B * chunks), dim3(256), 0, st, (const TI *)x, ldx, stat_sum,     \
+                     stat_sq, gamma, beta, mean, var, drop_mask, drop_scale, drop_thr, drop_seed, sample0, (TO *)y,   \
+                     ldy, (TO *)y2, ldy2, HW, C, eps, act, act2, slope, chunks, ppc)
+  if (dtype == CFD_BF16 && x_dtype == CFD_BF16) BNA_LAUNCH(bf16, bf16);
+  else if (dtype == CFD_BF16) BNA_LAUNCH(float, bf16);
+  else BNA_LAUNCH(float, float);
+#undef BNA_LAUNCH
   CFD_LAUNCH_CHECK();
   return CFD_OK;
 }

@@ -21,6 +21,7 @@ struct IgemmParams {
   int mtiles, ntiles, nclass, split_k;
   int cpt;             // K tiles per tap = Cin / BKE
   int nblocks;
+  float *stat_sum, *stat_sq;   // optional fused BatchNorm statistics [B][Cout] (accumulated with atomics), or NULL
 };
 
 // tap t of a class -> input-pixel offset (dy,dx) relative to the class-grid pixel * stride, and the
@@ -41,6 +42,15 @@ __host__ __device__ __forceinline__ void tap_geom(int kind, int ph, int pw, int 
   } else {
     dy = (t >> 2) - 1; dx = (t & 3) - 1; wtap = t;
   }
+}
+
+// sum over the 16 lanes of a DPP row (lanes that share lane>>4); every lane of the row gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+  return v;
 }
 
 __device__ __forceinline__ void glds16(const char *gsrc, char *lds_dst) {

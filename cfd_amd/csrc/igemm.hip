@@ -172,6 +172,43 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     }
   }
 
+  // ---- fused BatchNorm statistics (host guarantees: split_k == 1, Cout % 128 == 0, the 128 pixel rows of a
+  // tile lie in ONE sample, none ragged): see igemm256.hip
+  if (p.stat_sum) {
+    __syncthreads();
+    float *part = (float *)lds;   // [2][2 wm][128 n]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nl = wn * 64 + i * 16 + fq * 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[i][j][r] + bv[r];
+          t1 += v;
+          t2 = fmaf(v, v, t2);
+        }
+        t1 = row16_sum(t1);
+        t2 = row16_sum(t2);
+        if (fr == 0) {
+          part[(0 * 2 + wm) * 128 + nl + r] = t1;
+          part[(1 * 2 + wm) * 128 + nl + r] = t2;
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int which = tid >> 7, c = tid & 127;
+      const float *pp = part + which * 256 + c;
+      const float tot = pp[0] + pp[128];
+      const int b = m0 / (p.Hq * p.Wq);
+      atomicAdd((which ? p.stat_sq : p.stat_sum) + (size_t)b * p.Cout + n0 + c, tot);
+    }
+  }
+
   // ---- epilogue: lane holds channels n..n+3 (reg index) of pixel m
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -340,14 +377,32 @@ extern "C" int cfd_conv_suggest_split_k(const cfd_conv_desc *d) {
   return s;
 }
 
-extern "C" int cfd_conv_forward(const cfd_conv_desc *d, const void *x, const void *w, const float *bias, void *y,
-                                void *workspace, void *stream) {
+// fused statistics need: no split-K, every tile inside one sample, no ragged tile
+static bool stats_fusable(const IgemmParams &p, int dtype) {
+  if (p.split_k != 1) return false;
+  const int tile = use_igemm256(p, dtype) ? 256 : 128;
+  return (p.Hq * p.Wq) % tile == 0 && p.Cout % tile == 0;
+}
+
+extern "C" int cfd_conv_stats_fusable(const cfd_conv_desc *d) {
+  IgemmParams p;
+  if (fill_params(d, p) != CFD_OK) return 0;
+  return stats_fusable(p, d->dtype) ? 1 : 0;
+}
+
+static int conv_forward_impl(const cfd_conv_desc *d, const void *x, const void *w, const float *bias, void *y,
+                             void *workspace, float *stat_sum, float *stat_sq, void *stream) {
   IgemmParams p;
   int rc = fill_params(d, p);
   if (rc != CFD_OK) return rc;
   CFD_REQUIRE(x && w && y, "NULL tensor pointer");
   CFD_REQUIRE(p.split_k == 1 || workspace, "split_k=%d needs a workspace", p.split_k);
   p.x = (const char *)x; p.w = (const char *)w; p.bias = bias; p.y = (char *)y; p.ws = (float *)workspace;
+  if (stat_sum || stat_sq) {
+    CFD_REQUIRE(stat_sum && stat_sq, "both statistics buffers are needed");
+    CFD_REQUIRE(stats_fusable(p, d->dtype), "this shape cannot fuse BatchNorm statistics (ask cfd_conv_stats_fusable)");
+    p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+  }
   hipStream_t st = (hipStream_t)stream;
   const size_t shmem = 2 * STAGE_BYTES;
   if (use_igemm256(p, d->dtype)) {
@@ -379,4 +434,14 @@ extern "C" int cfd_conv_forward(const cfd_conv_desc *d, const void *x, const voi
     CFD_LAUNCH_CHECK();
   }
   return CFD_OK;
+}
+
+extern "C" int cfd_conv_forward(const cfd_conv_desc *d, const void *x, const void *w, const float *bias, void *y,
+                                void *workspace, void *stream) {
+  return conv_forward_impl(d, x, w, bias, y, workspace, nullptr, nullptr, stream);
+}
+
+extern "C" int cfd_conv_forward_stats(const cfd_conv_desc *d, const void *x, const void *w, const float *bias, void *y,
+                                      void *workspace, float *stat_sum, float *stat_sq, void *stream) {
+  return conv_forward_impl(d, x, w, bias, y, workspace, stat_sum, stat_sq, stream);
 }

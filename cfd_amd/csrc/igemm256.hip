@@ -235,6 +235,44 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   if (wr == 0) __builtin_amdgcn_s_barrier();
   wait_vmcnt<0>();   // the tail loads must not outlive the workgroup's LDS allocation
 
+  // ---- fused BatchNorm statistics (host guarantees: split_k == 1, the 256 pixel rows of a tile lie in ONE
+  // sample and none is ragged): per channel sum and sum of squares of (acc + bias) over the tile's pixels,
+  // reduced over the 16 pixel lanes by DPP, over the 4 pixel waves through LDS, then one atomic per channel
+  if (p.stat_sum) {
+    __syncthreads();   // every wave's LDS-DMA has landed and every fragment read is done: LDS is free
+    float *part = (float *)lds;   // [2][4 wc][256 n]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[i][j][r] + bv[r];
+          t1 += v;
+          t2 = fmaf(v, v, t2);
+        }
+        t1 = row16_sum(t1);
+        t2 = row16_sum(t2);
+        if (fr == 0) {
+          part[(0 * 4 + wc) * 256 + nl + r] = t1;
+          part[(1 * 4 + wc) * 256 + nl + r] = t2;
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int which = tid >> 8, c = tid & 255;
+      const float *pp = part + which * 1024 + c;
+      const float tot = pp[0] + pp[256] + pp[512] + pp[768];
+      const int b = m0 / (p.Hq * p.Wq);
+      atomicAdd((which ? p.stat_sq : p.stat_sum) + (size_t)b * p.Cout + n0 + c, tot);
+    }
+  }
+
   // ---- epilogue: lane holds channels n..n+3 (register index) of pixel m
 #pragma unroll
   for (int j = 0; j < 4; ++j) {

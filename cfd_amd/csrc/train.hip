@@ -416,11 +416,15 @@ __global__ void tap_dx_kernel(const float *__restrict__ d, const T *__restrict__
   }
 }
 
-// dw[t][c] += sum_rows d[row][t] * x[row][c];  block = chunk of rows, thread = 8 channels, 16 taps in registers
+// dw[t][c] += sum_rows d[row][t] * x[row][c];  block = chunk of rows, thread = 8 channels, 16 taps in registers.
+// The 256/CV row lanes of a block are summed through LDS, then every thread adds CONTIGUOUS channels with
+// atomics (one 256-B run per wave instruction: the shape global float atomics run at full rate with); with
+// <= 256 blocks the atomic traffic is a few MB instead of the ~130 MB a per-thread scatter costs.
 template <typename T>
 __global__ __launch_bounds__(256) void tap_dw_kernel(const float *__restrict__ d, const T *__restrict__ x, int ldx,
                                                     float *__restrict__ dw, int64_t rows, int C, int ntaps,
                                                     int rows_per_block) {
+  __shared__ float red[256 * 8];
   const int CV = C / 8;                // threads per row
   const int rpar = 256 / CV;           // rows in flight (host guarantees CV <= 256 and 256 % CV == 0)
   const int cv = threadIdx.x % CV, rl = threadIdx.x / CV;
@@ -431,27 +435,53 @@ __global__ __launch_bounds__(256) void tap_dw_kernel(const float *__restrict__ d
   for (int t = 0; t < 16; ++t)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
-  for (int64_t r = r0 + rl; r < r1; r += rpar) {
-    float xv[8];
-    IO8<T>::load(x + r * ldx + cv * 8, xv);
+  if (ntaps == 16) {
+    for (int64_t r = r0 + rl; r < r1; r += rpar) {
+      float xv[8];
+      IO8<T>::load(x + r * ldx + cv * 8, xv);
+      const f32x4 *dp = (const f32x4 *)(d + r * 16);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      if (t < ntaps) {
-        const float dv = d[r * ntaps + t];
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 dv = dp[q];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[t][i] = fmaf(dv, xv[i], acc[t][i]);
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[q * 4 + e][i] = fmaf(dv[e], xv[i], acc[q * 4 + e][i]);
+      }
+    }
+  } else {
+    for (int64_t r = r0 + rl; r < r1; r += rpar) {
+      float xv[8];
+      IO8<T>::load(x + r * ldx + cv * 8, xv);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        if (t < ntaps) {
+          const float dv = d[r * ntaps + t];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[t][i] = fmaf(dv, xv[i], acc[t][i]);
+        }
       }
     }
   }
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
-    if (t < ntaps)
+  for (int t = 0; t < 16; ++t) {
+    if (t < ntaps) {   // uniform
+      __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 8; ++i) atomicAdd(dw + (size_t)t * C + cv * 8 + i, acc[t][i]);
+      for (int i = 0; i < 8; ++i) red[rl * C + cv * 8 + i] = acc[t][i];
+      __syncthreads();
+      for (int c = threadIdx.x; c < C; c += 256) {
+        float sum = 0.f;
+        for (int k = 0; k < rpar; ++k) sum += red[k * C + c];
+        atomicAdd(dw + (size_t)t * C + c, sum);
+      }
+    }
+  }
 }
 
 // direct first-layer weight gradient: dw[co][tap][ci] += sum_pix dpre[pix][co] * patch(pix)[tap][ci], db[co] += sum dpre
-// (e1, c1, g1: Cin <= 2).  thread = output channel co, block = chunk of output pixels.
+// (e1, c1, g1: Cin <= 2).  thread = output channel co, block = chunk of output pixels; the block's partial
+// sums are transposed through LDS so that the atomics of a wave hit contiguous addresses.
 template <typename T, int KS, int S, int CIN>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ x2,
                                                               int cin1, const T *__restrict__ dpre, int ldd,
@@ -459,6 +489,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
                                                               int Hi, int Wi, int Ho, int Wo, int Cout, int pix_per_block) {
   constexpr int NW = KS * KS * CIN;
   __shared__ float patch[8][NW];
+  __shared__ float outb[256 * (NW + 1)];   // [co][NW] padded by one against bank conflicts
   const int64_t npix = (int64_t)B * Ho * Wo;
   const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
   const int64_t p1 = (p0 + pix_per_block < npix) ? p0 + pix_per_block : npix;
@@ -498,11 +529,14 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
       }
     }
   }
-  if (co < Cout) {
 #pragma unroll
-    for (int k = 0; k < NW; ++k) atomicAdd(dw + (size_t)co * NW + k, acc[k]);
-    if (db) atomicAdd(db + co, accb);
+  for (int k = 0; k < NW; ++k) outb[co * (NW + 1) + k] = acc[k];
+  __syncthreads();
+  for (int e = threadIdx.x; e < Cout * NW; e += 256) {
+    const int c = e / NW, k = e - c * NW;
+    atomicAdd(dw + e, outb[c * (NW + 1) + k]);
   }
+  if (co < Cout && db) atomicAdd(db + co, accb);
 }
 
 static inline int grid_for(int64_t total, int cap = 4096) {
@@ -694,7 +728,7 @@ extern "C" int cfd_tap_dw(const float *d, const void *x, int ldx, float *dw, int
   const int cv = C / 8;
   CFD_REQUIRE(cv <= 256 && 256 % cv == 0, "tap_dw: C=%d unsupported", C);
   hipStream_t st = (hipStream_t)stream;
-  int64_t rpb = (rows + 1023) / 1024;
+  int64_t rpb = (rows + 255) / 256;
   const int rpar = 256 / cv;
   if (rpb < 8 * rpar) rpb = 8 * rpar;
   const int blocks = (int)((rows + rpb - 1) / rpb);
@@ -716,7 +750,7 @@ extern "C" int cfd_conv_first_wgrad(const float *x, const float *x2, int cin1, i
   hipStream_t st = (hipStream_t)stream;
   const int Ho = Hi / stride, Wo = Wi / stride;
   const int64_t npix = (int64_t)B * Ho * Wo;
-  int64_t ppb = (npix + 1023) / 1024;
+  int64_t ppb = (npix + 255) / 256;
   if (ppb < 64) ppb = 64;
   ppb = (ppb + 7) / 8 * 8;
   const int blocks = (int)((npix + ppb - 1) / ppb);

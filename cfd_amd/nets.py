@@ -63,6 +63,35 @@ class _Net:
     def plan(self, B: int) -> dict:
         return self._plans.setdefault(B, {})
 
+    def bn_stats(self, pl: dict, B: int) -> dict:
+        """zeroed (sum, sumsq) fp32 (B, C) pairs, one per BatchNorm layer (slices of one flat buffer, one memset):
+        the conv epilogue accumulates the per-sample statistics into them where the shape allows it"""
+        buf = pl.get("bn_stats")
+        if buf is None:
+            tot = sum(2 * B * f for _n, f in self.bn_layers)
+            buf = pl["bn_stats"] = torch.empty(tot, dtype=torch.float32, device=self.device)
+            off, views = 0, {}
+            for n, f in self.bn_layers:
+                views[n] = (buf[off:off + B * f].view(B, f), buf[off + B * f:off + 2 * B * f].view(B, f))
+                off += 2 * B * f
+            pl["bn_stats_views"] = views
+        buf.zero_()
+        return pl["bn_stats_views"]
+
+    def conv_bn(self, pl: dict, st: dict, name: str, x: torch.Tensor, kind: int, f: int, raw: torch.Tensor, act: int,
+                out: torch.Tensor, **kw) -> None:
+        """conv -> BatchNorm(per-sample batch statistics) -> [dropout] -> activation(s).  Statistics come from the
+        conv epilogue (one read of `raw`) when the shape is fusable, else from bn_act's own first pass."""
+        P, B = self.params, raw.shape[0]
+        _y, fused = ops.conv_forward(x, P.c(name + ".kernel"), P.m(name + ".bias"), kind, f, out=raw, stats=st[name])
+        mean = self.buf(pl, "mean_" + name, (B, f), torch.float32)
+        var = self.buf(pl, "var_" + name, (B, f), torch.float32)
+        g, b = P.m(name + ".bn.gamma"), P.m(name + ".bn.beta")
+        if fused:
+            ops.bn_apply(raw, st[name], g, b, act, out=out, mean=mean, var=var, eps=BN_EPS, **kw)
+        else:
+            ops.bn_act(raw, g, b, act, out=out, mean=mean, var=var, eps=BN_EPS, **kw)
+
     def raw_dtype(self, h: int, w: int, c: int) -> torch.dtype:
         return torch.float32 if (self.dtype == torch.float32 or h * w * c <= RAW_F32_MAX_ELEMS) else self.dtype
 
@@ -87,6 +116,8 @@ class Generator(_Net):
             specs += _bn_specs(f"d{i}", f)
             c = f + s
         specs += [Spec("out.kernel", "convT", (4, 4, 1, c)), Spec("out.bias", "vec", (1,))]
+        self.bn_layers = [(f"e{i}", f) for i, f in enumerate(a["enc"], 1) if i > 1] + \
+                         [(f"d{i}", f) for i, (f, _d) in enumerate(a["dec"], 1)]
         super().__init__(specs, device, dtype, seed)
         self.params.no_transpose = frozenset({"e1.kernel", "out.kernel"})
 
@@ -113,6 +144,7 @@ class Generator(_Net):
         for i, ((f, _d), s) in enumerate(zip(dec, skips), 1):
             hh, ww = hh * 2, ww * 2
             cats.append(self.buf(pl, f"cat{i}", (B, hh, ww, f + s)))
+        st = self.bn_stats(pl, B)
         # ---- encoder
         h, w = h // 2, w // 2
         e = self.buf(pl, "e1", (B, h, w, enc[0]))
@@ -122,12 +154,10 @@ class Generator(_Net):
             f = enc[i - 1]
             h, w = h // 2, w // 2
             raw = self.buf(pl, f"raw_e{i}", (B, h, w, f), self.raw_dtype(h, w, f))
-            ops.conv_forward(e, P.c(f"e{i}.kernel"), P.m(f"e{i}.bias"), CONV_K4S2, f, out=raw)
-            e = self.buf(pl, f"e{i}", (B, h, w, f))
-            ops.bn_act(raw, P.m(f"e{i}.bn.gamma"), P.m(f"e{i}.bn.beta"), ACT_LEAKY, out=e,
-                       out2=cats[5 - i][..., dec[5 - i][0]:], act2=ACT_RELU, eps=BN_EPS,
-                       mean=self.buf(pl, f"mean_e{i}", (B, f), torch.float32),
-                       var=self.buf(pl, f"var_e{i}", (B, f), torch.float32))
+            e_out = self.buf(pl, f"e{i}", (B, h, w, f))
+            self.conv_bn(pl, st, f"e{i}", e, CONV_K4S2, f, raw, ACT_LEAKY, e_out,
+                         out2=cats[5 - i][..., dec[5 - i][0]:], act2=ACT_RELU)
+            e = e_out
         # ---- bottleneck (no BN): conv + ReLU
         h, w = h // 2, w // 2
         g = self.buf(pl, "b", (B, h, w, a["bott"]))
@@ -137,17 +167,14 @@ class Generator(_Net):
         for i, (f, drop) in enumerate(dec, 1):
             h, w = h * 2, w * 2
             raw = self.buf(pl, f"raw_d{i}", (B, h, w, f), self.raw_dtype(h, w, f))
-            ops.conv_forward(g, P.c(f"d{i}.kernel"), P.m(f"d{i}.bias"), CONVT_K4S2, f, out=raw)
             mask, rate = None, 0.0
             if drop:
                 rate = DROP_RATE
                 if masks is not None:
                     mask = masks[mi]
                 mi += 1
-            ops.bn_act(raw, P.m(f"d{i}.bn.gamma"), P.m(f"d{i}.bn.beta"), ACT_RELU, out=cats[i - 1][..., :f],
-                       drop_mask=mask, drop_rate=rate, drop_seed=seed * 16 + i, sample0=sample0, eps=BN_EPS,
-                       mean=self.buf(pl, f"mean_d{i}", (B, f), torch.float32),
-                       var=self.buf(pl, f"var_d{i}", (B, f), torch.float32))
+            self.conv_bn(pl, st, f"d{i}", g, CONVT_K4S2, f, raw, ACT_RELU, cats[i - 1][..., :f],
+                         drop_mask=mask, drop_rate=rate, drop_seed=seed * 16 + i, sample0=sample0)
             g = cats[i - 1]
         return ops.convT_out(g, P.c("out.kernel"), P.m("out.bias"), apply_sigmoid=True, want_logits=want_logits)
 
@@ -231,6 +258,7 @@ class Discriminator(_Net):
                 specs += _bn_specs(f"c{i}", f)
             c = f
         specs += [Spec("c6.kernel", "conv", (4, 4, c, 1)), Spec("c6.bias", "vec", (1,))]
+        self.bn_layers = [(f"c{i}", f) for i, (f, _s, bn) in enumerate(DISC, 1) if bn]
         super().__init__(specs, device, dtype, seed)
         self.params.no_transpose = frozenset({"c1.kernel", "c6.kernel"})
         self.params.flip_taps = frozenset({"c5.kernel"})
@@ -246,18 +274,18 @@ class Discriminator(_Net):
         h, w = self.H // 2, self.W // 2
         d = self.buf(pl, "c1", (B, h, w, DISC[0][0]))
         ops.conv_first(src, tgt, P.m("c1.kernel"), P.m("c1.bias"), DISC[0][0], 4, 2, ACT_LEAKY, self.dtype, out=d)
+        st = self.bn_stats(pl, B) if training else None
         for i in range(2, 6):
             f, s, _bn = DISC[i - 1]
             if s == 2:
                 h, w = h // 2, w // 2
             raw = self.buf(pl, f"raw_c{i}", (B, h, w, f), self.raw_dtype(h, w, f))
-            ops.conv_forward(d, P.c(f"c{i}.kernel"), P.m(f"c{i}.bias"), CONV_K4S2 if s == 2 else CONV_K4S1, f, out=raw)
-            d = self.buf(pl, f"c{i}", (B, h, w, f))
+            kind = CONV_K4S2 if s == 2 else CONV_K4S1
+            d_in, d = d, self.buf(pl, f"c{i}", (B, h, w, f))
             if training:
-                ops.bn_act(raw, P.m(f"c{i}.bn.gamma"), P.m(f"c{i}.bn.beta"), ACT_LEAKY, out=d, eps=BN_EPS,
-                           mean=self.buf(pl, f"mean_c{i}", (B, f), torch.float32),
-                           var=self.buf(pl, f"var_c{i}", (B, f), torch.float32))
+                self.conv_bn(pl, st, f"c{i}", d_in, kind, f, raw, ACT_LEAKY, d)
             else:
+                ops.conv_forward(d_in, P.c(f"c{i}.kernel"), P.m(f"c{i}.bias"), kind, f, out=raw)
                 ops.bn_act(raw, P.m(f"c{i}.bn.gamma"), P.m(f"c{i}.bn.beta"), ACT_LEAKY, out=d, eps=BN_EPS,
                            mean=P.m(f"c{i}.bn.moving_mean"), var=P.m(f"c{i}.bn.moving_var"), use_moving=True)
         logits = self.buf(pl, "logits", (B, h, w, 1), torch.float32)

@@ -106,8 +106,11 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 def conv_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kind: int, cout: int,
                  act: int = ACT_NONE, out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
-                 split_k: Optional[int] = None, slope: float = LEAKY_SLOPE) -> torch.Tensor:
-    """y = act(conv(x, w) + bias) on MFMA.  x NHWC (or (B,F) for DENSE); w packed [Cout][kh][kw][Cin]."""
+                 split_k: Optional[int] = None, slope: float = LEAKY_SLOPE,
+                 stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    """y = act(conv(x, w) + bias) on MFMA.  x NHWC (or (B,F) for DENSE); w packed [Cout][kh][kw][Cin].
+    stats = (sum, sumsq) fp32 (B, cout) buffers, zeroed by the caller: if the shape allows it the kernel also
+    accumulates the per-sample BatchNorm statistics into them and (y, True) is returned, else (y, False)."""
     lib = _lib.load()
     if kind == DENSE:
         B, cin = x.shape
@@ -125,6 +128,7 @@ def conv_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     if w.dtype != x.dtype:
         raise _lib.CfdError(f"weight dtype {w.dtype} != activation dtype {x.dtype}")
     d.split_k = int(split_k) if split_k else lib.cfd_conv_suggest_split_k(C.byref(d))
+    fused = stats is not None and act == ACT_NONE and bool(lib.cfd_conv_stats_fusable(C.byref(d)))
     ws = None
     if d.split_k > 1:
         nbytes = lib.cfd_conv_workspace_bytes(C.byref(d))
@@ -134,13 +138,17 @@ def conv_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     if _timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.cfd_conv_forward(C.byref(d), xp, _ptr(w), _ptr(bias), yp, _ptr(ws), _stream()), "cfd_conv_forward")
+    if fused:
+        check(lib.cfd_conv_forward_stats(C.byref(d), xp, _ptr(w), _ptr(bias), yp, _ptr(ws), _ptr(stats[0]),
+                                         _ptr(stats[1]), _stream()), "cfd_conv_forward_stats")
+    else:
+        check(lib.cfd_conv_forward(C.byref(d), xp, _ptr(w), _ptr(bias), yp, _ptr(ws), _stream()), "cfd_conv_forward")
     if _timer is not None:
         e1.record()
         taps = {CONV_K4S2: 16, CONV_K4S1: 16, CONV_K3S1: 9, CONVT_K4S2: 4, DENSE: 1, 5: 16}[kind]
         opix = out.numel() // cout
         _timer.records.append((kind, 2.0 * opix * cout * taps * cin, e0, e1))
-    return out
+    return (out, fused) if stats is not None else out
 
 
 def pack_conv_weight(keras_hwio: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -223,6 +231,31 @@ def bn_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int, o
     check(_lib.load().cfd_bn_act(xp, ldx, _DT[x.dtype], _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var),
                                  int(use_moving), _ptr(drop_mask), drop_rate, drop_seed, sample0, yp, ldy, y2p, ldy2,
                                  B, H * W, Cc, eps, act, act2, slope, _DT[out.dtype], _stream()), "cfd_bn_act")
+    return out
+
+
+def bn_apply(x: torch.Tensor, stats: Tuple[torch.Tensor, torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+             act: int, out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, act2: int = ACT_RELU,
+             drop_mask: Optional[torch.Tensor] = None, drop_rate: float = 0.0, drop_seed: int = 0, sample0: int = 0,
+             mean: Optional[torch.Tensor] = None, var: Optional[torch.Tensor] = None, eps: float = 1e-3,
+             slope: float = LEAKY_SLOPE) -> torch.Tensor:
+    """bn_act for a conv output whose (sum, sumsq) statistics were accumulated by conv_forward(stats=...)."""
+    B, H, W, Cc = x.shape
+    xp, ldx = _nhwc(x)
+    if out is None:
+        out = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device)
+    yp, ldy = _nhwc(out)
+    y2p, ldy2 = (None, 0) if out2 is None else _nhwc(out2)
+    if out2 is not None and out2.dtype != out.dtype:
+        raise _lib.CfdError("out and out2 must share a dtype")
+    if drop_mask is not None and (drop_mask.dtype != torch.uint8 or not drop_mask.is_contiguous()):
+        raise _lib.CfdError("drop_mask must be dense uint8 NHWC")
+    if drop_mask is not None and drop_rate == 0.0:
+        drop_rate = 0.5
+    check(_lib.load().cfd_bn_apply(xp, ldx, _DT[x.dtype], _ptr(stats[0]), _ptr(stats[1]), _ptr(gamma), _ptr(beta),
+                                   _ptr(mean), _ptr(var), _ptr(drop_mask), drop_rate, drop_seed, sample0, yp, ldy,
+                                   y2p, ldy2, B, H * W, Cc, eps, act, act2, slope, _DT[out.dtype], _stream()),
+          "cfd_bn_apply")
     return out
 
 

@@ -78,6 +78,15 @@ int cfd_conv_suggest_split_k(const cfd_conv_desc *desc);
 int cfd_conv_forward(const cfd_conv_desc *desc, const void *x, const void *w, const float *bias, void *y,
                      void *workspace, void *stream);
 
+/* Same as cfd_conv_forward, and additionally accumulates (atomics; the caller zeroes them) the per-sample,
+ * per-channel sum and sum of squares of the stored pre-activation into stat_sum / stat_sq, fp32 [B][Cout]:
+ * the batch statistics BatchNormalization(training=True) needs (generator.py:20-21,33), taken from the fp32
+ * accumulators so the conv output is not re-read for them.  Only shapes with cfd_conv_stats_fusable() != 0
+ * (no split-K, whole output tiles inside one sample); desc->act must be CFD_ACT_NONE. */
+int cfd_conv_stats_fusable(const cfd_conv_desc *desc);
+int cfd_conv_forward_stats(const cfd_conv_desc *desc, const void *x, const void *w, const float *bias, void *y,
+                           void *workspace, float *stat_sum, float *stat_sq, void *stream);
+
 /* weight re-layout: Keras Conv2D (kh,kw,Cin,Cout) fp32 -> packed [Cout][kh][kw][Cin] of `dtype` */
 int cfd_pack_conv_weight(const float *keras_hwio, void *packed, int kh, int kw, int cin, int cout, int dtype,
                          void *stream);
@@ -126,6 +135,13 @@ int cfd_bn_act(const void *x, int ldx, int x_dtype, const float *gamma, const fl
                int use_moving, const uint8_t *drop_mask, float drop_rate, uint64_t drop_seed, int64_t sample0,
                void *y, int ldy, void *y2, int ldy2, int B, int HW, int C, float eps, int act, int act2,
                float leaky_slope, int dtype, void *stream);
+/* cfd_bn_act for a conv output whose statistics came from cfd_conv_forward_stats: one coalesced read of x.
+ * stat_sum / stat_sq fp32 [B][C]; mean / var (may be NULL) receive the per-sample statistics [B][C] that
+ * cfd_bn_act_bwd needs.  Same dropout / activation arguments as cfd_bn_act.  C in {64,128,...,2048}. */
+int cfd_bn_apply(const void *x, int ldx, int x_dtype, const float *stat_sum, const float *stat_sq, const float *gamma,
+                 const float *beta, float *mean, float *var, const uint8_t *drop_mask, float drop_rate,
+                 uint64_t drop_seed, int64_t sample0, void *y, int ldy, void *y2, int ldy2, int B, int HW, int C,
+                 float eps, int act, int act2, float leaky_slope, int dtype, void *stream);
 /* the keep-mask (0/1 bytes, [B][HW][C]) that cfd_bn_act's RNG mode applies for the same arguments */
 int cfd_dropout_mask(uint8_t *mask, int64_t sample0, int B, int HW, int C, float rate, uint64_t seed, void *stream);
 

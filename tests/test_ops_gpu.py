@@ -218,6 +218,58 @@ def test_bn_act(B, H, W, C, drop, dtype):
     assert relerr(y2.float().cpu(), ref2) <= TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype,force256", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("kind,B,H,W,cin,cout,drop", [
+    ("k4s2", 3, 32, 32, 64, 256, False),    # 256 output pixels per sample: one tile per sample
+    ("k4s2", 2, 32, 64, 64, 256, False),    # 512 per sample
+    ("convT", 2, 16, 16, 64, 256, True),    # class grid 256 per sample, dropout (RNG mode)
+])
+def test_conv_stats_bn_apply(kind, B, H, W, cin, cout, drop, dtype, force256):
+    """BatchNorm statistics fused into the conv epilogue + bn_apply == conv -> oracle BatchNorm (+dropout, acts)"""
+    from cfd_amd import ops
+    dev = "cuda"
+    x = q(rnd((B, H, W, cin), 1), dtype)
+    bias = rnd((cout,), 3, 0.5)
+    p = {"l.bn.gamma": 1 + 0.1 * rnd((cout,), 4), "l.bn.beta": 0.1 * rnd((cout,), 5)}
+    if kind == "convT":
+        wk = q(rnd((4, 4, cout, cin), 2, 0.05), dtype)
+        pre = O.conv2d_transpose_same(x, wk, bias)
+        wp, code = ops.pack_convT_weight(wk.to(dev), dtype), ops.CONVT_K4S2
+    else:
+        wk = q(rnd((4, 4, cin, cout), 2, 0.05), dtype)
+        pre = O.conv2d_same(x, wk, bias, 2)
+        wp, code = ops.pack_conv_weight(wk.to(dev), dtype), ops.CONV_K4S2
+    st = {}
+    ref = O.batchnorm(pre, p, "l", True, True, st)
+    Bo, Ho, Wo, _ = pre.shape
+    ops.set_tuning(ops.TUNE_IGEMM256, force256)
+    try:
+        stats = (torch.zeros((B, cout), device=dev), torch.zeros((B, cout), device=dev))
+        raw = torch.empty(tuple(pre.shape), dtype=torch.float32, device=dev)
+        _, fused = ops.conv_forward(x.to(dev).to(dtype), wp, bias.to(dev), code, cout, out=raw, stats=stats,
+                                    split_k=1)
+    finally:
+        ops.set_tuning(ops.TUNE_IGEMM256, -1)
+    assert fused, "shape was expected to be fusable"
+    n = Ho * Wo
+    torch.cuda.synchronize()
+    assert relerr(stats[0].cpu() / n, st["l"][0]) <= 2e-5
+    mean, var = torch.empty((B, cout), device=dev), torch.empty((B, cout), device=dev)
+    cat = torch.zeros((Bo, Ho, Wo, 2 * cout), dtype=dtype, device=dev)
+    seed = 77
+    y = ops.bn_apply(raw, stats, p["l.bn.gamma"].to(dev), p["l.bn.beta"].to(dev), ops.ACT_LEAKY, out=cat[..., :cout],
+                     out2=cat[..., cout:], act2=ops.ACT_RELU, drop_rate=0.5 if drop else 0.0, drop_seed=seed,
+                     sample0=3, mean=mean, var=var)
+    if drop:
+        m = ops.dropout_mask((Bo, Ho, Wo, cout), 0.5, seed, sample0=3).cpu().float()
+        ref = ref * m * 2.0
+    torch.cuda.synchronize()
+    assert relerr(mean.cpu(), st["l"][0]) <= 2e-5
+    assert relerr(var.cpu(), st["l"][1]) <= 2e-4
+    assert relerr(y.float().cpu(), O.leaky(ref)) <= TOL[dtype]
+    assert relerr(cat[..., cout:].float().cpu(), torch.relu(ref)) <= TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool2(dtype):
     from cfd_amd import ops
