@@ -60,7 +60,7 @@ __device__ __forceinline__ void glds16(const char *gsrc, char *lds_dst) {
 
 // igemm256.hip
 bool igemm256_eligible(const IgemmParams &p, int dtype);
-int igemm256_launch(const IgemmParams &p, hipStream_t st);
+int igemm256_launch(const IgemmParams &p, int dtype, hipStream_t st);
 int igemm256_block_count(const IgemmParams &p);
 
 }  // namespace cfd

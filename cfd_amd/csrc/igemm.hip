@@ -360,7 +360,8 @@ static bool use_igemm256(const IgemmParams &p, int dtype) {
   // and the launch fills at least half the chip; below that the 128x128 kernel's 2 blocks/CU hide more
   const int blocks = cdiv(p.M, 256) * (p.Cout / 256) * p.nclass;
   const int s = split_k_256(p);
-  return blocks * s >= 128 && (p.ntaps * p.cpt) / s >= 32;
+  // (an f32 K tile is 8x the MFMA time of a bf16 one, so a much shorter slice already amortises the prologue)
+  return blocks * s >= 128 && (p.ntaps * p.cpt) / s >= (dtype == CFD_BF16 ? 32 : 8);
 }
 
 extern "C" int cfd_conv_suggest_split_k(const cfd_conv_desc *d) {
@@ -406,7 +407,7 @@ static int conv_forward_impl(const cfd_conv_desc *d, const void *x, const void *
   hipStream_t st = (hipStream_t)stream;
   const size_t shmem = 2 * STAGE_BYTES;
   if (use_igemm256(p, d->dtype)) {
-    rc = igemm256_launch(p, st);
+    rc = igemm256_launch(p, d->dtype, st);
     if (rc != CFD_OK) return rc;
   } else if (d->dtype == CFD_BF16) {
     static bool attr_done = false;

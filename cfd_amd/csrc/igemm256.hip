@@ -1,4 +1,4 @@
-// bf16 implicit-GEMM convolution, 256(n) x 256(m) tile, 8 waves in two ping-pong groups.
+// bf16 / f32 implicit-GEMM convolution, 256(n) x 256(m) tile, 8 waves in two ping-pong groups.
 //
 // Same GEMM view, operand roles and NHWC epilogue as igemm.hip (weights = MFMA A side, gathered
 // activations = B side); used for the large layers (Cout % 256 == 0), where the 128x128 kernel's
@@ -27,6 +27,7 @@
 //     so the counts stay uniform.
 #include "common.h"
 #include "igemm.h"
+#include <type_traits>
 
 namespace cfd {
 
@@ -55,10 +56,26 @@ __device__ __forceinline__ void bload16(__amdgpu_buffer_rsrc_t rsrc, unsigned vo
                                            (int)soff, 0, 0);
 }
 
-template <int PD>
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
+  return c;
+}
+
+// T = bf16: K tile = 64 elements, mfma_f32_16x16x32_bf16.  T = float: K tile = 32 elements, exact-f32
+// mfma_f32_16x16x4f32; a 16-B fragment read then feeds four MFMAs (lane group fq supplies k = 16 s + 4 fq + e
+// on BOTH operands -- any consistent k assignment sums to the same dot product).  Rows are 128 B either way.
+template <typename T, int PD>
 __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const IgemmParams &p = P.g;
+  constexpr int ES = sizeof(T);
+  constexpr int EPC = 16 / ES;     // elements per 16-B chunk
+  constexpr int BKE = 128 / ES;    // K elements per tile row
+  typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type frag_t;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -96,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   unsigned avoff[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    avoff[r] = (unsigned)(((n0 + (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow) * p.Kw + chunk * 8) * 2);
+    avoff[r] = (unsigned)(((n0 + (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow) * p.Kw + chunk * EPC) * ES);
   // B side: four pixel rows per lane, r = half*2 + piece
   unsigned rowoff[4], vmask[4], cur[4];
 #pragma unroll
@@ -108,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
     const int rem = mm - b * (p.Hq * p.Wq);
     const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
     const int y0 = qy * S, x0 = qx * S;
-    rowoff[r] = (unsigned)((((b * p.Hi + y0) * p.Wi + x0) * p.ldx + chunk * 8) * 2);
+    rowoff[r] = (unsigned)((((b * p.Hi + y0) * p.Wi + x0) * p.ldx + chunk * EPC) * ES);
     unsigned msk = 0;
 #pragma clang loop vectorize(disable) unroll(disable)
     for (int t = 0; t < p.ntaps; ++t) {
@@ -125,9 +142,9 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   unsigned s_a = 0, s_b = 0;                // scalar byte offsets: A = (wtap*Cin + c*64)*2, B = c*128
   auto tap_switch = [&]() {
     const int info = P.tapinfo[cls][iss_t];
-    s_a = (unsigned)(((info & 255) * p.Cin + iss_c * 64) * 2);
+    s_a = (unsigned)(((info & 255) * p.Cin + iss_c * BKE) * ES);
     s_b = (unsigned)(iss_c * 128);
-    const int tapx = (info >> 8) * p.ldx * 2;
+    const int tapx = (info >> 8) * p.ldx * ES;
 #pragma unroll
     for (int r = 0; r < 4; ++r) cur[r] = ((vmask[r] >> iss_t) & 1u) ? rowoff[r] + (unsigned)tapx : OOB;
   };
@@ -180,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // second group runs one barrier behind
 
-  bf16x8 a[4][2], b0[2][2], b1[2][2];
+  frag_t a[4][2], b0[2][2], b1[2][2];
 
 #define CFD_PHASE(ST, PH, READS, MFMAS)                                                \
     {                                                                                  \
@@ -200,26 +217,26 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
       _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
           _Pragma("unroll") for (int j = 0; j < 2; ++j)                                \
-            acc[AI + i][BJ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], BREG[j][s], acc[AI + i][BJ + j], 0, 0, 0);
+            acc[AI + i][BJ + j] = mma(a[i][s], BREG[j][s], acc[AI + i][BJ + j]);
 #define CFD_KTILE(ST)                                                                  \
     CFD_PHASE(ST, 0,                                                                   \
       _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                  \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                  \
-          b0[j][s] = *(const bf16x8 *)(brd[s] + ST * ST_BYTES + 1 * HT_BYTES + j * 2048); \
+          b0[j][s] = *(const frag_t *)(brd[s] + ST * ST_BYTES + 1 * HT_BYTES + j * 2048); \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
-          a[i][s] = *(const bf16x8 *)(ard[s] + ST * ST_BYTES + 0 * HT_BYTES + i * 2048); \
+          a[i][s] = *(const frag_t *)(ard[s] + ST * ST_BYTES + 0 * HT_BYTES + i * 2048); \
       },                                                                               \
       CFD_MFMA(0, 0, b0))                                                              \
     CFD_PHASE(ST, 1,                                                                   \
       _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                  \
-          b1[j][s] = *(const bf16x8 *)(brd[s] + ST * ST_BYTES + 2 * HT_BYTES + j * 2048); \
+          b1[j][s] = *(const frag_t *)(brd[s] + ST * ST_BYTES + 2 * HT_BYTES + j * 2048); \
       ,                                                                                \
       CFD_MFMA(0, 2, b1))                                                              \
     CFD_PHASE(ST, 2,                                                                   \
       _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
-          a[i][s] = *(const bf16x8 *)(ard[s] + ST * ST_BYTES + 3 * HT_BYTES + i * 2048); \
+          a[i][s] = *(const frag_t *)(ard[s] + ST * ST_BYTES + 3 * HT_BYTES + i * 2048); \
       ,                                                                                \
       CFD_MFMA(4, 2, b1))                                                              \
     CFD_PHASE(ST, 3, , CFD_MFMA(4, 0, b0))
@@ -307,19 +324,21 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   }
 }
 
-static int64_t x_bytes(const IgemmParams &p) { return (((int64_t)p.B * p.Hi * p.Wi - 1) * p.ldx + p.Cin) * 2; }
-static int64_t w_bytes(const IgemmParams &p) { return (int64_t)p.Cout * p.Kw * 2; }
+static int64_t x_bytes(const IgemmParams &p, int es) { return (((int64_t)p.B * p.Hi * p.Wi - 1) * p.ldx + p.Cin) * es; }
+static int64_t w_bytes(const IgemmParams &p, int es) { return (int64_t)p.Cout * p.Kw * es; }
 
 bool igemm256_eligible(const IgemmParams &p, int dtype) {
-  return dtype == CFD_BF16 && p.Cout % 256 == 0 && p.Cin % 64 == 0 && p.ntaps <= 16 &&
-         x_bytes(p) < (1LL << 31) && w_bytes(p) < (1LL << 31);
+  const int es = dtype == CFD_BF16 ? 2 : 4;
+  return p.Cout % 256 == 0 && p.Cin % (128 / es) == 0 && p.ntaps <= 16 && x_bytes(p, es) < (1LL << 31) &&
+         w_bytes(p, es) < (1LL << 31);
 }
 
 int igemm256_block_count(const IgemmParams &p) {
   return cdiv(p.M, 256) * (p.Cout / 256) * p.nclass * p.split_k;
 }
 
-int igemm256_launch(const IgemmParams &pin, hipStream_t st) {
+int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
+  const int es = dtype == CFD_BF16 ? 2 : 4;
   Igemm256Params P;
   memset(&P, 0, sizeof(P));
   P.g = pin;
@@ -327,8 +346,8 @@ int igemm256_launch(const IgemmParams &pin, hipStream_t st) {
   p.mtiles = cdiv(p.M, 256);
   p.ntiles = p.Cout / 256;
   p.nblocks = p.mtiles * p.ntiles * p.nclass * p.split_k;
-  P.xbytes = (unsigned)x_bytes(p);
-  P.wbytes = (unsigned)w_bytes(p);
+  P.xbytes = (unsigned)x_bytes(p, es);
+  P.wbytes = (unsigned)w_bytes(p, es);
   for (int cls = 0; cls < p.nclass; ++cls)
     for (int t = 0; t < p.ntaps; ++t) {
       int dy, dx, wt;
@@ -340,14 +359,17 @@ int igemm256_launch(const IgemmParams &pin, hipStream_t st) {
   const size_t shmem = 2 * ST_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<bf16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<bf16, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<float, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     attr_done = true;
   }
-  if (tuning(CFD_TUNE_IGEMM256_PD) == 5)
-    hipLaunchKernelGGL(igemm256_kernel<5>, dim3(p.nblocks), dim3(512), shmem, st, P);
+  if (dtype == CFD_F32)
+    hipLaunchKernelGGL((igemm256_kernel<float, 6>), dim3(p.nblocks), dim3(512), shmem, st, P);
+  else if (tuning(CFD_TUNE_IGEMM256_PD) == 5)
+    hipLaunchKernelGGL((igemm256_kernel<bf16, 5>), dim3(p.nblocks), dim3(512), shmem, st, P);
   else
-    hipLaunchKernelGGL(igemm256_kernel<6>, dim3(p.nblocks), dim3(512), shmem, st, P);
+    hipLaunchKernelGGL((igemm256_kernel<bf16, 6>), dim3(p.nblocks), dim3(512), shmem, st, P);
   CFD_LAUNCH_CHECK();
   return CFD_OK;
 }

@@ -75,7 +75,7 @@ def test_conv_forward(kind, B, H, W, cin, cout, dtype):
     assert relerr(y.cpu(), ref) <= 1e-4
 
 
-@pytest.mark.parametrize("pd", [5, 6])
+@pytest.mark.parametrize("dtype,pd", [(torch.bfloat16, 5), (torch.bfloat16, 6), (torch.float32, 6)])
 @pytest.mark.parametrize("kind,B,H,W,cin,cout,split_k", [
     ("k4s2", 2, 16, 64, 64, 256, 1),      # two full 256-row tiles, one tap-major K sweep
     ("k4s2", 3, 12, 20, 128, 512, 1),     # ragged last m tile (M = 180), two n tiles
@@ -86,11 +86,11 @@ def test_conv_forward(kind, B, H, W, cin, cout, dtype):
     ("convT", 1, 1, 8, 64, 256, 2),       # 1x8 input, split-K
     ("dense", 5, 1, 1, 1024, 256, 1),     # dense, M = 5
 ])
-def test_conv_forward_igemm256(kind, B, H, W, cin, cout, split_k, pd):
-    """the 256x256 ping-pong bf16 kernel (igemm256.hip), forced on, against the oracle; bias + LeakyReLU fused,
-    bf16 output written into a channel slice of a wider buffer"""
+def test_conv_forward_igemm256(kind, B, H, W, cin, cout, split_k, dtype, pd):
+    """the 256x256 ping-pong kernel (igemm256.hip; bf16 and exact-f32 MFMA), forced on, against the oracle; bias +
+    LeakyReLU fused, output written into a channel slice of a wider buffer"""
     from cfd_amd import ops
-    dev, dtype = "cuda", torch.bfloat16
+    dev = "cuda"
     x = q(rnd((B, H, W, cin), 1), dtype)
     bias = rnd((cout,), 3, 0.1)
     ops.set_tuning(ops.TUNE_IGEMM256, 1)
@@ -218,7 +218,8 @@ def test_bn_act(B, H, W, C, drop, dtype):
     assert relerr(y2.float().cpu(), ref2) <= TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype,force256", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("dtype,force256", [(torch.float32, 0), (torch.float32, 1), (torch.bfloat16, 0),
+                                            (torch.bfloat16, 1)])
 @pytest.mark.parametrize("kind,B,H,W,cin,cout,drop", [
     ("k4s2", 3, 32, 32, 64, 256, False),    # 256 output pixels per sample: one tile per sample
     ("k4s2", 2, 32, 64, 64, 256, False),    # 512 per sample
