@@ -9,7 +9,7 @@
 namespace cfd {
 
 // ---------------------------------------------------------------------------------------------
-// conv_first: block = one output row segment of TX pixels; the input patch (KS rows x
+// conv_first: tile = one output row segment of TX pixels (a block walks many tiles); the input patch (KS rows x
 // ((TX-1)*S+KS) cols x CIN) is staged in LDS with zero padding (TF 'same': pad 1 before),
 // each thread keeps the weights of its CPT output channels in registers.
 // ---------------------------------------------------------------------------------------------
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
                                                          int cin1, const float *__restrict__ w,
                                                          const float *__restrict__ bias, TO *__restrict__ y, int ldy,
                                                          TO *__restrict__ y2, int ldy2, int Hi, int Wi, int Ho, int Wo,
-                                                         int Cout, int act, int act2, float slope) {
+                                                         int Cout, int act, int act2, float slope, int ntiles) {
   constexpr int TX = 32;
   constexpr int PW = (TX - 1) * S + KS;
   constexpr int NW = KS * KS * CIN;
@@ -31,13 +31,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
   const int pstep = 256 / CG;
 
   const int xtiles = (Wo + TX - 1) / TX;
-  int bid = blockIdx.x;
-  const int xt = bid % xtiles; bid /= xtiles;
-  const int oy = bid % Ho;
-  const int b = bid / Ho;
-  const int ox0 = xt * TX;
 
-  // weights of my channels: wreg[c][tap*CIN + ci]
+  // weights of my channels: wreg[c][tap*CIN + ci] -- loaded ONCE per block; the block then walks many tiles
+  // (a per-tile block re-read 128 KB of weights to write 32 KB of output)
   float wreg[CPT][NW];
   float breg[CPT];
 #pragma unroll
@@ -48,51 +44,60 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
     breg[c] = bias ? bias[cg * CPT + c] : 0.f;
   }
 
-  // stage the patch
-  const int iy0 = oy * S - 1, ix0 = ox0 * S - 1;
-  for (int e = tid; e < KS * PW * CIN; e += 256) {
-    const int ci = e % CIN;
-    const int px = (e / CIN) % PW;
-    const int py = e / (CIN * PW);
-    const int iy = iy0 + py, ix = ix0 + px;
-    float v = 0.f;
-    if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) {
-      const size_t pix = ((size_t)b * Hi + iy) * Wi + ix;
-      v = (ci < cin1) ? x[pix * cin1 + ci] : x2[pix * (CIN - cin1) + (ci - cin1)];
-    }
-    patch[py][px][ci] = v;
-  }
-  __syncthreads();
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
+    const int xt = bid % xtiles; bid /= xtiles;
+    const int oy = bid % Ho;
+    const int b = bid / Ho;
+    const int ox0 = xt * TX;
 
-  for (int px = slot; px < TX; px += pstep) {
-    const int ox = ox0 + px;
-    if (ox >= Wo) break;
-    float accv[CPT];
+    // stage the patch
+    const int iy0 = oy * S - 1, ix0 = ox0 * S - 1;
+    __syncthreads();   // the previous tile's readers are done
+    for (int e = tid; e < KS * PW * CIN; e += 256) {
+      const int ci = e % CIN;
+      const int px = (e / CIN) % PW;
+      const int py = e / (CIN * PW);
+      const int iy = iy0 + py, ix = ix0 + px;
+      float v = 0.f;
+      if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) {
+        const size_t pix = ((size_t)b * Hi + iy) * Wi + ix;
+        v = (ci < cin1) ? x[pix * cin1 + ci] : x2[pix * (CIN - cin1) + (ci - cin1)];
+      }
+      patch[py][px][ci] = v;
+    }
+    __syncthreads();
+
+    for (int px = slot; px < TX; px += pstep) {
+      const int ox = ox0 + px;
+      if (ox >= Wo) break;
+      float accv[CPT];
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) accv[c] = breg[c];
+      for (int c = 0; c < CPT; ++c) accv[c] = breg[c];
 #pragma unroll
-    for (int kh = 0; kh < KS; ++kh)
+      for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < KS; ++kw)
+        for (int kw = 0; kw < KS; ++kw)
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) {
-          const float v = patch[kh][px * S + kw][ci];
+          for (int ci = 0; ci < CIN; ++ci) {
+            const float v = patch[kh][px * S + kw][ci];
 #pragma unroll
-          for (int c = 0; c < CPT; ++c) accv[c] = fmaf(v, wreg[c][(kh * KS + kw) * CIN + ci], accv[c]);
-        }
-    const size_t opix = ((size_t)b * Ho + oy) * Wo + ox;
-    TO o[CPT];
+            for (int c = 0; c < CPT; ++c) accv[c] = fmaf(v, wreg[c][(kh * KS + kw) * CIN + ci], accv[c]);
+          }
+      const size_t opix = ((size_t)b * Ho + oy) * Wo + ox;
+      TO o[CPT];
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) o[c] = from_f32<TO>(apply_act(accv[c], act, slope));
-    TO *dst = y + opix * ldy + cg * CPT;
+      for (int c = 0; c < CPT; ++c) o[c] = from_f32<TO>(apply_act(accv[c], act, slope));
+      TO *dst = y + opix * ldy + cg * CPT;
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) dst[c] = o[c];  // contiguous CPT elements: the compiler merges into one wide store
-    if (y2) {
+      for (int c = 0; c < CPT; ++c) dst[c] = o[c];  // contiguous CPT elements: the compiler merges into one wide store
+      if (y2) {
 #pragma unroll
-      for (int c = 0; c < CPT; ++c) o[c] = from_f32<TO>(apply_act(accv[c], act2, slope));
-      TO *dst2 = y2 + opix * ldy2 + cg * CPT;
+        for (int c = 0; c < CPT; ++c) o[c] = from_f32<TO>(apply_act(accv[c], act2, slope));
+        TO *dst2 = y2 + opix * ldy2 + cg * CPT;
 #pragma unroll
-      for (int c = 0; c < CPT; ++c) dst2[c] = o[c];
+        for (int c = 0; c < CPT; ++c) dst2[c] = o[c];
+      }
     }
   }
 }
@@ -104,13 +109,14 @@ static int launch_conv_first(const float *x, const float *x2, int cin1, const fl
   const int Ho = Hi / S, Wo = Wi / S;
   const int CG = Cout / CPT;
   CFD_REQUIRE(Cout % CPT == 0 && CG <= 256 && 256 % CG == 0, "conv_first: Cout=%d unsupported", Cout);
-  const int blocks = B * Ho * ((Wo + 31) / 32);
+  const int ntiles = B * Ho * ((Wo + 31) / 32);
+  const int blocks = ntiles < 2048 ? ntiles : 2048;
   if (out_dtype == CFD_BF16)
     hipLaunchKernelGGL((conv_first_kernel<KS, S, CIN, CPT, bf16>), dim3(blocks), dim3(256), 0, st, x, x2, cin1, w, bias,
-                       (bf16 *)y, ldy, (bf16 *)y2, ldy2, Hi, Wi, Ho, Wo, Cout, act, act2, slope);
+                       (bf16 *)y, ldy, (bf16 *)y2, ldy2, Hi, Wi, Ho, Wo, Cout, act, act2, slope, ntiles);
   else
     hipLaunchKernelGGL((conv_first_kernel<KS, S, CIN, CPT, float>), dim3(blocks), dim3(256), 0, st, x, x2, cin1, w,
-                       bias, (float *)y, ldy, (float *)y2, ldy2, Hi, Wi, Ho, Wo, Cout, act, act2, slope);
+                       bias, (float *)y, ldy, (float *)y2, ldy2, Hi, Wi, Ho, Wo, Cout, act, act2, slope, ntiles);
   CFD_LAUNCH_CHECK();
   return CFD_OK;
 }
