@@ -151,6 +151,32 @@ def cpu_baseline_train(seconds_budget=25.0):
                 sample=f"{n} U training steps at batch 1 (G predict + 2 D updates + GAN update), oracle (PyTorch-CPU fp32)")
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the MFMA conv kernels for this workload, from the committed PMC passes
+    (profiles/*_<workload>_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same
+    command, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  None when no profile of the workload is committed."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_summary.json")))
+    if not fs:
+        return None, None
+    try:
+        ks = json.load(open(fs[-1]))["kernels"]
+    except Exception:
+        return None, None
+    n = b = 0
+    busy = []
+    for name, k in ks.items():
+        if name.startswith(("igemm", "wgrad")) and "hbm_read_bytes_per_launch" in k:
+            n += k["launches"]
+            b += k["launches"] * (k["hbm_read_bytes_per_launch"] + k.get("hbm_write_bytes_per_launch", 0))
+            if "mfma_busy_frac" in k:
+                busy.append((k["total_us"], k["mfma_busy_frac"]))
+    if not n:
+        return None, None
+    mb = sum(t * f for t, f in busy) / sum(t for t, _ in busy) if busy else None
+    return round(b / n), (round(mb, 4) if mb is not None else None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,8 +231,10 @@ def main():
         sm = kt.summary()
         achieved = sm["total_flops"] / (sm["total_ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[wl["dtype"]]
-        roof = dict(bound="mfma", kernel="igemm_kernel+wgrad_kernel" if train else "igemm_kernel", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                    frac=round(achieved / peak, 4), traffic=None,
+        traffic, busy = pmc_traffic(args.workload)
+        roof = dict(bound="mfma", kernel="igemm256_kernel+igemm_kernel" + ("+wgrad_kernel" if train else ""),
+                    achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
+                    frac=round(achieved / peak, 4), traffic=traffic, mfma_busy_frac_pmc=busy,
                     launches_per_step=sm["launches"] // min(args.steps, 5),
                     avg_launch_us=round(sm["total_ms"] * 1e3 / sm["launches"], 2))
 
