@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcfd_amd.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 CONV_K4S2, CONV_K4S1, CONV_K3S1, CONVT_K4S2, DENSE, CONV_K4S1_BWD = 0, 1, 2, 3, 4, 5
-TUNE_IGEMM256, TUNE_IGEMM256_PD = 0, 1
+TUNE_IGEMM256, TUNE_IGEMM256_PD, TUNE_WGRAD256 = 0, 1, 2
 
 
 class ConvDesc(C.Structure):
@@ -54,6 +54,8 @@ SIGNATURES = {
     "cfd_cast_copy": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
     "cfd_conv_wgrad": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
     "cfd_conv_wgrad_suggest_split": (_i, [C.POINTER(ConvDesc)]),
+    "cfd_conv_wgrad_workspace_bytes": (_i64, [C.POINTER(ConvDesc), _i]),
+    "cfd_conv_wgrad_ws": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp, _vp]),
     "cfd_transpose_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cfd_colsum": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp]),
     "cfd_bn_act_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _f, C.c_uint64, _i64, _vp, _i, _vp,

@@ -68,7 +68,7 @@ __device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) {
 // T = bf16: K tile = 64 elements, mfma_f32_16x16x32_bf16.  T = float: K tile = 32 elements, exact-f32
 // mfma_f32_16x16x4f32; a 16-B fragment read then feeds four MFMAs (lane group fq supplies k = 16 s + 4 fq + e
 // on BOTH operands -- any consistent k assignment sums to the same dot product).  Rows are 128 B either way.
-template <typename T, int PD>
+template <typename T, int PD, bool DIAG = false, int NPH = 4>
 __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const IgemmParams &p = P.g;
@@ -187,31 +187,46 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: H0 .. H(PD-1)
+  // ---- prologue: H0 .. H(PD-1)   (NPH == 2: H0 .. H5, and H0..H2 must have landed)
+  constexpr int PRO = NPH == 2 ? 6 : PD;
 #pragma unroll
-  for (int h = 0; h < PD; ++h) {
+  for (int h = 0; h < PRO; ++h) {
     issue(h & 3, (h >> 2) & 1);
     if ((h & 3) == 3) iss_advance();
   }
-  wait_vmcnt<2 * (PD - 2)>();   // H0, H1 landed
+  if constexpr (NPH == 2) wait_vmcnt<6>(); else wait_vmcnt<2 * (PD - 2)>();
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // second group runs one barrier behind
 
   frag_t a[4][2], b0[2][2], b1[2][2];
 
+  // diagnostic build only (DIAG): cycle stamps around the four segments of a phase, summed per wave
+  unsigned long long dg[5] = {0, 0, 0, 0, 0}, dt0 = 0, dt1 = 0;
+#define CFD_STAMP(dst)                                                                 \
+      if constexpr (DIAG) {                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dst) :: "memory");  \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+      }
 #define CFD_PHASE(ST, PH, READS, MFMAS)                                                \
     {                                                                                  \
+      CFD_STAMP(dt0)                                                                   \
       READS                                                                            \
       issue((PH + PD) & 3, (ST + ((PH + PD) >> 2)) & 1);                               \
       if (((PH + PD) & 3) == 3) iss_advance();                                         \
+      CFD_STAMP(dt1) if constexpr (DIAG) { dg[0] += dt1 - dt0; }                       \
       wait_vmcnt<2 * (PD - 2)>();                                                      \
+      CFD_STAMP(dt0) if constexpr (DIAG) { dg[1] += dt0 - dt1; }                       \
       __builtin_amdgcn_s_barrier();                                                    \
+      CFD_STAMP(dt1) if constexpr (DIAG) { dg[2] += dt1 - dt0; }                       \
       __builtin_amdgcn_sched_barrier(0);                                               \
       __builtin_amdgcn_s_setprio(1);                                                   \
       MFMAS                                                                            \
       __builtin_amdgcn_s_setprio(0);                                                   \
       __builtin_amdgcn_sched_barrier(0);                                               \
+      CFD_STAMP(dt0) if constexpr (DIAG) { dg[3] += dt0 - dt1; }                       \
       __builtin_amdgcn_s_barrier();                                                    \
+      CFD_STAMP(dt1) if constexpr (DIAG) { dg[4] += dt1 - dt0; }                       \
     }
 #define CFD_MFMA(AI, BJ, BREG)                                                         \
       _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
@@ -241,14 +256,78 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
       CFD_MFMA(4, 2, b1))                                                              \
     CFD_PHASE(ST, 3, , CFD_MFMA(4, 0, b0))
 
-  for (int k = 0; k < nkt; k += 2) {
-    CFD_KTILE(0)
-    if (k + 1 >= nkt) break;
-    CFD_KTILE(1)
+  // NPH == 2: two phases of 32 MFMAs per K tile (half as many barrier intervals as the 4 x 16 schedule: each
+  // interval carries ~170 cycles of barrier / pipeline-restart overhead on top of its MFMA time).
+  //   phase A: read A0, B0, B1; issue H(4k+6), H(4k+7) (B1, A1 of K tile k+1);  MFMA A0 x (B0 | B1)
+  //   phase B: read A1;         issue H(4k+8), H(4k+9) (A0, B0 of K tile k+2);  MFMA A1 x (B0 | B1)
+  // Fragment reads are retired (lgkmcnt(0)) BEFORE the phase's first barrier, so a slot may be restaged one phase
+  // after its last read; vmcnt(8) / vmcnt(6) leave 4 / 3 half tiles in flight.
+#define CFD_PHASE2(ST, SLOTA, STA, SLOTB, STB, VM, READS, MFMAS)                        \
+    {                                                                                  \
+      CFD_STAMP(dt0)                                                                   \
+      READS                                                                            \
+      issue(SLOTA, STA); issue(SLOTB, STB);                                            \
+      if (SLOTB == 3) iss_advance();                                                   \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+      CFD_STAMP(dt1) if constexpr (DIAG) { dg[0] += dt1 - dt0; }                       \
+      wait_vmcnt<VM>();                                                                \
+      CFD_STAMP(dt0) if constexpr (DIAG) { dg[1] += dt0 - dt1; }                       \
+      __builtin_amdgcn_s_barrier();                                                    \
+      CFD_STAMP(dt1) if constexpr (DIAG) { dg[2] += dt1 - dt0; }                       \
+      __builtin_amdgcn_sched_barrier(0);                                               \
+      __builtin_amdgcn_s_setprio(1);                                                   \
+      MFMAS                                                                            \
+      __builtin_amdgcn_s_setprio(0);                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                               \
+      CFD_STAMP(dt0) if constexpr (DIAG) { dg[3] += dt0 - dt1; }                       \
+      __builtin_amdgcn_s_barrier();                                                    \
+      CFD_STAMP(dt1) if constexpr (DIAG) { dg[4] += dt1 - dt0; }                       \
+    }
+#define CFD_KTILE2(ST)                                                                 \
+    CFD_PHASE2(ST, 2, (ST + 1) & 1, 3, (ST + 1) & 1, 8,                                \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                  \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                  \
+          b0[j][s] = *(const frag_t *)(brd[s] + ST * ST_BYTES + 1 * HT_BYTES + j * 2048); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
+          a[i][s] = *(const frag_t *)(ard[s] + ST * ST_BYTES + 0 * HT_BYTES + i * 2048); \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                  \
+          b1[j][s] = *(const frag_t *)(brd[s] + ST * ST_BYTES + 2 * HT_BYTES + j * 2048); \
+      },                                                                               \
+      CFD_MFMA(0, 0, b0) CFD_MFMA(0, 2, b1))                                           \
+    CFD_PHASE2(ST, 0, ST, 1, ST, 6,                                                    \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
+          a[i][s] = *(const frag_t *)(ard[s] + ST * ST_BYTES + 3 * HT_BYTES + i * 2048); \
+      ,                                                                                \
+      CFD_MFMA(4, 0, b0) CFD_MFMA(4, 2, b1))
+
+  if constexpr (NPH == 2) {
+    for (int k = 0; k < nkt; k += 2) {
+      CFD_KTILE2(0)
+      if (k + 1 >= nkt) break;
+      CFD_KTILE2(1)
+    }
+  } else {
+    for (int k = 0; k < nkt; k += 2) {
+      CFD_KTILE(0)
+      if (k + 1 >= nkt) break;
+      CFD_KTILE(1)
+    }
   }
+#undef CFD_KTILE2
+#undef CFD_PHASE2
 #undef CFD_KTILE
 #undef CFD_MFMA
 #undef CFD_PHASE
+#undef CFD_STAMP
+  if constexpr (DIAG) {
+    // stamps leave the kernel only through the workspace (split_k must be 1): [block][wave][8]
+    if (lane == 0 && p.ws) {
+      unsigned long long *o = (unsigned long long *)p.ws + ((size_t)blockIdx.x * 8 + wave) * 8;
+      for (int i = 0; i < 5; ++i) o[i] = dg[i];
+      o[5] = (unsigned long long)nkt;
+    }
+  }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   wait_vmcnt<0>();   // the tail loads must not outlive the workgroup's LDS allocation
 
@@ -357,19 +436,26 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
       P.tapdx[cls][t] = (short)dx;
     }
   const size_t shmem = 2 * ST_BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<bf16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<bf16, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<float, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_done = true;
-  }
-  if (dtype == CFD_F32)
-    hipLaunchKernelGGL((igemm256_kernel<float, 6>), dim3(p.nblocks), dim3(512), shmem, st, P);
-  else if (tuning(CFD_TUNE_IGEMM256_PD) == 5)
-    hipLaunchKernelGGL((igemm256_kernel<bf16, 5>), dim3(p.nblocks), dim3(512), shmem, st, P);
-  else
-    hipLaunchKernelGGL((igemm256_kernel<bf16, 6>), dim3(p.nblocks), dim3(512), shmem, st, P);
+  const int pdt = tuning(CFD_TUNE_IGEMM256_PD);
+  // variants (cfd_set_tuning(CFD_TUNE_IGEMM256_PD, v)): default / 26 = two phases of 32 MFMAs per K tile;
+  // 5, 6 = four phases of 16, prefetch distance 5 / 6 half tiles; 106, 126 = diagnostic builds with cycle stamps
+#define CFD_LAUNCH256(...)                                                                                          \
+  do {                                                                                                              \
+    static bool done_ = false;                                                                                      \
+    if (!done_) {                                                                                                   \
+      CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<__VA_ARGS__>,                                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                         \
+      done_ = true;                                                                                                 \
+    }                                                                                                               \
+    hipLaunchKernelGGL((igemm256_kernel<__VA_ARGS__>), dim3(p.nblocks), dim3(512), shmem, st, P);                   \
+  } while (0)
+  if (dtype == CFD_F32) CFD_LAUNCH256(float, 6, false, 4);
+  else if (pdt == 126) CFD_LAUNCH256(bf16, 6, true, 2);
+  else if (pdt == 106) CFD_LAUNCH256(bf16, 6, true, 4);
+  else if (pdt == 5) CFD_LAUNCH256(bf16, 5, false, 4);
+  else if (pdt == 6) CFD_LAUNCH256(bf16, 6, false, 4);
+  else CFD_LAUNCH256(bf16, 6, false, 2);
+#undef CFD_LAUNCH256
   CFD_LAUNCH_CHECK();
   return CFD_OK;
 }

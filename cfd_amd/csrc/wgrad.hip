@@ -15,6 +15,7 @@
 // Grid = co tiles x ci tiles x taps x split_m.  split_m > 1 accumulates with fp32 atomics into a
 // zeroed buffer (summation order then varies run to run); split_m == 1 stores.
 #include "common.h"
+#include "wgrad256.h"
 
 namespace cfd {
 
@@ -214,8 +215,8 @@ static void make_magic(int d, unsigned long long &magic, int &shift) {
 using namespace cfd;
 
 /* declared in include/cfd_amd.h */
-extern "C" int cfd_conv_wgrad(const cfd_conv_desc *d, const void *x, const void *dy, float *dw, int split_m,
-                              void *stream) {
+static int conv_wgrad_impl(const cfd_conv_desc *d, const void *x, const void *dy, float *dw, int split_m,
+                           void *workspace, void *stream) {
   CFD_REQUIRE(d && x && dy && dw, "NULL pointer");
   CFD_REQUIRE(d->dtype == CFD_BF16 || d->dtype == CFD_F32, "bad dtype");
   CFD_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Cin > 0 && d->Cout > 0, "non-positive shape");
@@ -223,6 +224,10 @@ extern "C" int cfd_conv_wgrad(const cfd_conv_desc *d, const void *x, const void 
   CFD_REQUIRE(d->Cin % epc == 0 && d->Cout % epc == 0 && d->ldx % epc == 0 && d->ldy % epc == 0,
               "wgrad: Cin/Cout/ldx/ldy must be multiples of %d (Cin=%d Cout=%d)", epc, d->Cin, d->Cout);
   CFD_REQUIRE(split_m >= 1, "split_m must be >= 1");
+  {
+    Wgrad256Params p2;
+    if (wgrad256_selected(d, p2)) return wgrad256_launch(p2, x, dy, dw, split_m, (float *)workspace, (hipStream_t)stream);
+  }
   WgradParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char *)x; p.dy = (const char *)dy; p.dw = dw;
@@ -272,8 +277,28 @@ extern "C" int cfd_conv_wgrad(const cfd_conv_desc *d, const void *x, const void 
   return CFD_OK;
 }
 
+extern "C" int cfd_conv_wgrad(const cfd_conv_desc *d, const void *x, const void *dy, float *dw, int split_m,
+                              void *stream) {
+  return conv_wgrad_impl(d, x, dy, dw, split_m, nullptr, stream);
+}
+
+extern "C" int cfd_conv_wgrad_ws(const cfd_conv_desc *d, const void *x, const void *dy, float *dw, int split_m,
+                                 void *workspace, void *stream) {
+  return conv_wgrad_impl(d, x, dy, dw, split_m, workspace, stream);
+}
+
+extern "C" int64_t cfd_conv_wgrad_workspace_bytes(const cfd_conv_desc *d, int split_m) {
+  Wgrad256Params p2;
+  if (d && wgrad256_selected(d, p2)) return wgrad256_workspace_bytes(p2, split_m);
+  return 0;
+}
+
 extern "C" int cfd_conv_wgrad_suggest_split(const cfd_conv_desc *d) {
   if (!d) return 1;
+  {
+    Wgrad256Params p2;
+    if (wgrad256_selected(d, p2)) return wgrad256_suggest_split(p2);
+  }
   int ntaps, Hm, Wm;
   switch (d->kind) {
     case CFD_CONV_K4S2: ntaps = 16; Hm = d->Hi / 2; Wm = d->Wi / 2; break;

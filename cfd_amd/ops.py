@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, CONV_K3S1, CONV_K4S1, CONV_K4S2, CONVT_K4S2,
-                   DENSE, F32, TUNE_IGEMM256, TUNE_IGEMM256_PD, ConvDesc, check)
+                   DENSE, F32, TUNE_IGEMM256, TUNE_IGEMM256_PD, TUNE_WGRAD256, ConvDesc, check)
 
 LEAKY_SLOPE = 0.2
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
@@ -347,12 +347,14 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kind: int, cout: int, dw: torc
     d = ConvDesc(kind=kind, dtype=_DT[x.dtype], out_dtype=_DT[x.dtype], B=B, Hi=Hi, Wi=Wi, Cin=cin, Cout=cout,
                  ldx=ldx, ldy=ldy, act=0, leaky_slope=0.0, split_k=1)
     s = int(split_m) if split_m else lib.cfd_conv_wgrad_suggest_split(C.byref(d))
-    if s > 1:
+    wsb = lib.cfd_conv_wgrad_workspace_bytes(C.byref(d), s) if s > 1 else 0
+    ws = _workspace(wsb, x.device) if wsb > 0 else None
+    if s > 1 and ws is None:
         dw.zero_()  # memset node on the stream; the kernel accumulates with atomics
     if _timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.cfd_conv_wgrad(C.byref(d), xp, yp, _ptr(dw), s, _stream()), "cfd_conv_wgrad")
+    check(lib.cfd_conv_wgrad_ws(C.byref(d), xp, yp, _ptr(dw), s, _ptr(ws), _stream()), "cfd_conv_wgrad_ws")
     if _timer is not None:
         e1.record()
         opix = (dy.numel() // cout) if kind != CONVT_K4S2 else (x.numel() // cin)

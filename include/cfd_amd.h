@@ -38,8 +38,9 @@ const char *cfd_last_error(void);
 /* Tuning / A-B switches (no counterpart in the reference; process-wide, not thread-safe against running calls).
  *   CFD_TUNE_IGEMM256     -1 heuristic (default) | 0 never | 1 whenever eligible: use the 256x256 ping-pong
  *                         bf16 implicit-GEMM kernel instead of the 128x128 one
- *   CFD_TUNE_IGEMM256_PD  prefetch distance of that kernel in half tiles: 5 (default) or 6 */
-typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_COUNT = 2 } cfd_tuning_key;
+ *   CFD_TUNE_IGEMM256_PD  schedule variant of that kernel (see igemm256.hip; default = two phases per K tile)
+ *   CFD_TUNE_WGRAD256     -1 heuristic | 0 never | 1 whenever eligible: the 256x256 ping-pong weight-gradient kernel */
+typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_WGRAD256 = 2, CFD_TUNE_COUNT = 3 } cfd_tuning_key;
 int cfd_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------
@@ -168,6 +169,12 @@ int cfd_cast_copy(const void *x, int ldx, int x_dtype, void *y, int ldy, int y_d
  * > 1 accumulates with atomics into a buffer the caller zeroed. */
 int cfd_conv_wgrad(const cfd_conv_desc *desc, const void *x, const void *dy, float *dw, int split_m, void *stream);
 int cfd_conv_wgrad_suggest_split(const cfd_conv_desc *desc);
+/* Same, with scratch for split_m > 1: when cfd_conv_wgrad_workspace_bytes(desc, split_m) > 0 and `workspace` holds
+ * that many bytes, the partial tiles are stored and summed in a fixed order -- dw is overwritten (no zeroing
+ * needed), the result is bitwise reproducible and no atomics are issued.  Otherwise identical to cfd_conv_wgrad. */
+int64_t cfd_conv_wgrad_workspace_bytes(const cfd_conv_desc *desc, int split_m);
+int cfd_conv_wgrad_ws(const cfd_conv_desc *desc, const void *x, const void *dy, float *dw, int split_m,
+                      void *workspace, void *stream);
 /* dst[Cin][taps][Cout] = src[Cout][taps][Cin], taps reversed when flip != 0 */
 int cfd_transpose_weight(const void *src, void *dst, int Cout, int taps, int Cin, int flip, int dtype, void *stream);
 /* out[c] += sum_m x[m][c]: bias gradients (out must be zeroed by the caller) */

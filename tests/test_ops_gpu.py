@@ -75,7 +75,7 @@ def test_conv_forward(kind, B, H, W, cin, cout, dtype):
     assert relerr(y.cpu(), ref) <= 1e-4
 
 
-@pytest.mark.parametrize("dtype,pd", [(torch.bfloat16, 5), (torch.bfloat16, 6), (torch.float32, 6)])
+@pytest.mark.parametrize("dtype,pd", [(torch.bfloat16, 5), (torch.bfloat16, 6), (torch.bfloat16, 26), (torch.float32, 6)])
 @pytest.mark.parametrize("kind,B,H,W,cin,cout,split_k", [
     ("k4s2", 2, 16, 64, 64, 256, 1),      # two full 256-row tiles, one tap-major K sweep
     ("k4s2", 3, 12, 20, 128, 512, 1),     # ragged last m tile (M = 180), two n tiles

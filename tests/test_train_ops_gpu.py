@@ -93,6 +93,48 @@ def test_conv_backward(kind, B, H, W, cin, cout, dtype):
     assert relerr(db, dy.reshape(-1, cout).sum(0)) <= 1e-4
 
 
+WG256 = [
+    ("k4s2", 2, 16, 32, 256, 256, 1),    # reduction grid 8x16, gathered X with padding on every side
+    ("k4s2", 3, 8, 128, 256, 512, 3),    # Wm = 64: a K tile is one grid row; ragged split
+    ("k4s1", 2, 4, 32, 256, 256, 2),     # asymmetric 'same' padding
+    ("k3s1", 2, 8, 16, 256, 256, 1),     # 9 taps
+    ("convT", 2, 8, 16, 256, 256, 2),    # gathered operand = dY (co side)
+    ("convT", 1, 1, 8, 512, 256, 1),     # M = 8 < one K tile: ragged tail rows must read as zero
+    ("dense", 70, 1, 1, 256, 256, 1),    # 1x1 grid, M = 70 (ragged)
+]
+
+
+@pytest.mark.parametrize("kind,B,H,W,cin,cout,split", WG256)
+def test_conv_wgrad256(kind, B, H, W, cin, cout, split):
+    """the 256x256 ping-pong bf16 weight-gradient kernel (wgrad256.hip), forced on, vs autograd"""
+    from cfd_amd import ops
+    dev, dtype = "cuda", torch.bfloat16
+    code = {"k4s2": ops.CONV_K4S2, "k4s1": ops.CONV_K4S1, "k3s1": ops.CONV_K3S1, "convT": ops.CONVT_K4S2,
+            "dense": ops.DENSE}[kind]
+    x = q(rnd((B, H, W, cin), 1), dtype).requires_grad_(True)
+    wk = q(rnd(_kernel_shape(kind, cin, cout), 2, 0.05), dtype).requires_grad_(True)
+    y = _fwd_ref(kind, x, wk, torch.zeros(cout))
+    dy = q(rnd(y.shape, 4), dtype)
+    y.backward(dy)
+    pack = {"dense": ops.pack_dense_weight, "convT": ops.pack_convT_weight}.get(kind, ops.pack_conv_weight)
+    dw_ref = pack(wk.grad.to(dev), torch.float32)
+    xd = x.detach().to(dev).to(dtype)
+    dyd = dy.to(dev).to(dtype)
+    if kind == "dense":
+        xd = xd.reshape(B, cin)
+    # operands as channel slices of wider buffers (the concat layout the nets use)
+    xw = torch.zeros(xd.shape[:-1] + (cin + 64,), dtype=dtype, device=dev)
+    xw[..., 64:] = xd
+    dw = torch.zeros(dw_ref.shape, dtype=torch.float32, device=dev)
+    ops.set_tuning(ops.TUNE_WGRAD256, 1)
+    try:
+        ops.conv_wgrad(xw[..., 64:], dyd, code, cout, dw, split_m=split)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning(ops.TUNE_WGRAD256, -1)
+    assert relerr(dw, dw_ref) <= 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,C,drop,two", [(2, 4, 32, 128, False, True), (3, 2, 16, 64, True, False),
                                               (1, 16, 64, 64, False, False)])
