@@ -27,8 +27,8 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 PEAK_HBM_GBS = 8000.0
 # forward GFLOP per sample of the GEMM-shaped layers only (SURVEY.md §2.1 minus the direct first/last layers)
 WORKLOADS = {
-    "infer_pd_fp32": dict(nets=["P", "DeltaP"], dtype="f32", batch=32),
-    "infer_all_bf16": dict(nets=["U", "P", "DeltaP"], dtype="bf16", batch=64),
+    "infer_pd_fp32": dict(nets=["P", "DeltaP"], dtype="f32", batch=128),
+    "infer_all_bf16": dict(nets=["U", "P", "DeltaP"], dtype="bf16", batch=128),
     # configs[3]: U surrogate training, bf16, data parallel; one step = the reference's four calls
     # (U/train.py:119-125): G predict, D on real, D on fake, composite GAN update -- incl. Adam and all-reduce
     "train_u_bf16": dict(nets=["U", "D"], dtype="bf16", batch=16, train=True),

@@ -21,6 +21,7 @@ ARCH = "gfx950"
 # per-file extra flags
 EXTRA = {
     "resample.hip": ["-ffp-contract=off"],   # bit-exact fp64: no fused multiply-add
+    "dataset.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-Wno-unused-variable", "-fno-gpu-rdc"]

@@ -249,6 +249,21 @@ int cfd_resample_nearest(const double *pts, const int64_t *case_offsets, int nca
                          const double *z_final, int W, const double *z_samples, int S, double tol1, double tol2,
                          double p_convert, double *out, void *workspace, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Dataset build: what utils.load_data computes per case after parsing the CSV (utils.py:89-103).
+ *   p            fp64 [ncase][H][W]: the `p_convert` column reshaped (device)
+ *   sdf          fp64 [ncase][H][W]: signed distance of pts = (p > 0 ? -1 : +1) with cell size `cell` (= 4/H,
+ *                utils.py:101): the model input.  Exact Euclidean distance to the contour half a cell from either
+ *                centre; skfmm.distance (fast marching, absent here) differs by its discretisation error.
+ *   delta_p      fp64 [ncase]: mean(p[:,0]) - mean(p[:,-1]) in numpy's summation order (utils.py:97)
+ *   flags        int  [ncase]: bit 0 = some cell is fluid, bit 1 = some cell is solid; a case with flags != 3 has
+ *                no zero contour (skfmm raises there; the host mirror does too)
+ *   workspace    cfd_dataset_workspace_bytes(ncase, H, W) bytes
+ * ---------------------------------------------------------------------------------- */
+int64_t cfd_dataset_workspace_bytes(int ncase, int H, int W);
+int cfd_dataset_grids(const double *p, int ncase, int H, int W, double cell, double *sdf, double *delta_p, int *flags,
+                      void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

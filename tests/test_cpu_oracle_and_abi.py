@@ -87,3 +87,25 @@ def test_oracle_forward_small():
     assert d.shape == (2, 4, 4, 1)
     pc = O.init_cnn(image_shape=(64, 64, 1))
     assert O.cnn_forward(pc, x).shape == (2, 1)
+
+
+def test_oracle_signed_distance_analytic():
+    """oracle/dataset.signed_distance (parity unpinned vs skfmm): straight channel and a disc, against the analytic
+    distance to the half-cell contour"""
+    from oracle import dataset as OD
+    H, W, dx = 64, 96, 4.0 / 64
+    # straight channel: fluid rows 20..43 -> contour at rows 19.5 and 43.5
+    phi = np.ones((H, W)); phi[20:44] = -1.0
+    d = OD.signed_distance(phi, dx)
+    y = np.arange(H)[:, None] * np.ones((1, W))
+    ref = np.where(phi < 0, -np.minimum(y - 19.5, 43.5 - y), np.minimum(np.abs(y - 19.5), np.abs(y - 43.5))) * dx
+    assert np.allclose(d, ref, atol=1e-12)
+    # disc of solid in fluid: exact EDT is within one cell diagonal of the analytic distance to the circle
+    yy, xx = np.mgrid[0:H, 0:W]
+    r = np.hypot(yy - 32, xx - 48)
+    phi = np.where(r < 12.0, 1.0, -1.0)
+    d = OD.signed_distance(phi, dx)
+    assert np.abs(d - (12.0 - r) * dx).max() <= 1.0 * dx
+    assert ((d < 0) == (phi < 0)).all()
+    with pytest.raises(ValueError):
+        OD.signed_distance(np.ones((8, 8)), dx)

@@ -312,3 +312,30 @@ def test_resample_no_slices_raises():
     pts = np.array([[0.0, 0.0, 0.02525, 1.0, 1.0]])  # no point within 1e-4 of any slice
     with pytest.raises(ValueError):
         ops.resample_nearest([pts], 8, 16)
+
+
+@pytest.mark.parametrize("H,W", [(64, 512), (128, 1024), (16, 40)])
+def test_dataset_grids_bit_exact(H, W):
+    """sign mask -> signed distance + DeltaP (utils.py:89-103) on the GPU vs the numpy/scipy restatement
+    (oracle/dataset.py): integer distance transform + one fp64 sqrt, numpy's summation order -> bit-exact"""
+    from cfd_amd import ops, synthetic
+    from oracle import dataset as OD
+    ps = []
+    for s in range(3):
+        _sdf, _u, p = synthetic.model_case(s, H, W)
+        p = p.astype(np.float64) * (1.0 + 0.01 * np.random.default_rng(s).standard_normal(p.shape))
+        ps.append(np.where(p > 0, p, 0.0))
+    # a case with an island of solid cells inside the fluid and fluid cells touching the border
+    q4 = ps[0].copy()
+    q4[H // 2 - 2:H // 2 + 2, W // 3:W // 3 + 5] = 0.0
+    q4[0, :7] = 0.5
+    ps.append(q4)
+    p = np.stack(ps)
+    sdf, dp = ops.dataset_grids(p, cell=4.0 / H)
+    for i in range(len(ps)):
+        ref_sdf, _p, _u, ref_dp = OD.grids_from_table(ps[i].ravel(), ps[i].ravel(), H, W)
+        assert np.array_equal(sdf[i].view(np.uint64), ref_sdf.view(np.uint64)), f"sdf case {i}"
+        assert dp[i] == ref_dp, f"DeltaP case {i}: {dp[i]!r} vs {ref_dp!r}"
+    # no zero contour: skfmm raises, so do we
+    with pytest.raises(ValueError):
+        ops.dataset_grids(np.ones((1, H, W)), cell=4.0 / H)
