@@ -62,5 +62,6 @@ __device__ __forceinline__ void glds16(const char *gsrc, char *lds_dst) {
 bool igemm256_eligible(const IgemmParams &p, int dtype);
 int igemm256_launch(const IgemmParams &p, int dtype, hipStream_t st);
 int igemm256_block_count(const IgemmParams &p);
+int igemm256_ntile(const IgemmParams &p);
 
 }  // namespace cfd

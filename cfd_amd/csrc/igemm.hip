@@ -345,7 +345,7 @@ extern "C" int64_t cfd_conv_workspace_bytes(const cfd_conv_desc *d) {
 // split-K choice for the 256x256 kernel: one 512-thread block per CU, so fill ~256 blocks, and keep the K loop
 // of a slice long enough (>= 8 K tiles) to amortise the pipeline prologue
 static int split_k_256(const IgemmParams &p) {
-  const int blocks = cdiv(p.M, 256) * (p.Cout / 256) * p.nclass;
+  const int blocks = cdiv(p.M, 256) * (p.Cout / igemm256_ntile(p)) * p.nclass;
   const int ktiles = p.ntaps * p.cpt;
   int s = 1;
   while (blocks * s * 2 <= 256 && ktiles / (s * 2) >= 8) s *= 2;
@@ -358,7 +358,7 @@ static bool use_igemm256(const IgemmParams &p, int dtype) {
   if (mode >= 0) return mode != 0;
   // measured (scripts/layer_bench.py, B = 16..64): the ping-pong kernel wins once a slice runs >= 32 K tiles
   // and the launch fills at least half the chip; below that the 128x128 kernel's 2 blocks/CU hide more
-  const int blocks = cdiv(p.M, 256) * (p.Cout / 256) * p.nclass;
+  const int blocks = cdiv(p.M, 256) * (p.Cout / igemm256_ntile(p)) * p.nclass;
   const int s = split_k_256(p);
   // (an f32 K tile is 8x the MFMA time of a bf16 one, so a much shorter slice already amortises the prologue)
   return blocks * s >= 128 && (p.ntaps * p.cpt) / s >= (dtype == CFD_BF16 ? 32 : 8);
@@ -381,8 +381,8 @@ extern "C" int cfd_conv_suggest_split_k(const cfd_conv_desc *d) {
 // fused statistics need: no split-K, every tile inside one sample, no ragged tile
 static bool stats_fusable(const IgemmParams &p, int dtype) {
   if (p.split_k != 1) return false;
-  const int tile = use_igemm256(p, dtype) ? 256 : 128;
-  return (p.Hq * p.Wq) % tile == 0 && p.Cout % tile == 0;
+  if (use_igemm256(p, dtype)) return (p.Hq * p.Wq) % 256 == 0;   // Cout is a multiple of its n tile
+  return (p.Hq * p.Wq) % 128 == 0 && p.Cout % 128 == 0;
 }
 
 extern "C" int cfd_conv_stats_fusable(const cfd_conv_desc *d) {

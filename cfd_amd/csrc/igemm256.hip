@@ -403,17 +403,248 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 128(n) x 256(m) variant for layers with Cout = 128 (mod 256): P d5, DeltaP g3, ...
+// Same ping-pong machinery; a K tile is three half tiles (A, B0, B1 = 48 KiB), three stages (144 KiB), and ONE
+// phase of 32 MFMAs per K tile:
+//   wave (wr, wc) owns n rows wr*64 + [0,64) and m rows wc*64 + [0,64) (B half wc/2): 4 x 4 fragments.
+//   phase k: read stage k%3; issue the six loads of K tile k+2 into stage (k+2)%3 (last read in phase k-1, whose
+//   fragment reads every wave retired before its first barrier); lgkmcnt(0); vmcnt(6) (K tile k+1 landed); barrier;
+//   32 MFMAs; barrier.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int ST3_BYTES = 3 * HT_BYTES;
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const IgemmParams &p = P.g;
+  constexpr int ES = sizeof(T);
+  constexpr int EPC = 16 / ES;
+  constexpr int BKE = 128 / ES;
+  typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type frag_t;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = p.nblocks, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = bid % p.ntiles; bid /= p.ntiles;
+  const int mt = bid % p.mtiles; bid /= p.mtiles;
+  const int cls = bid % p.nclass;
+  const int sk = bid / p.nclass;
+  const int ph = cls >> 1, pw = cls & 1;
+  const int m0 = mt * 256, n0 = nt * 128;
+  const int S = (p.kind == CFD_CONV_K4S2) ? 2 : 1;
+
+  const int ktiles = p.ntaps * p.cpt;
+  const int kbeg = (int)((int64_t)ktiles * sk / p.split_k);
+  const int kend = (int)((int64_t)ktiles * (sk + 1) / p.split_k);
+  const int nkt = kend - kbeg;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)P.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)P.wbytes, 0x00020000);
+
+  const int lrow = lane >> 3;
+  const int chunk = (lane & 7) ^ lrow;
+  unsigned avoff[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+    avoff[r] = (unsigned)(((n0 + r * 64 + wave * 8 + lrow) * p.Kw + chunk * EPC) * ES);
+  unsigned rowoff[4], vmask[4], cur[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow;
+    const bool mv = m < p.M;
+    const int mm = mv ? m : 0;
+    const int b = mm / (p.Hq * p.Wq);
+    const int rem = mm - b * (p.Hq * p.Wq);
+    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    const int y0 = qy * S, x0 = qx * S;
+    rowoff[r] = (unsigned)((((b * p.Hi + y0) * p.Wi + x0) * p.ldx + chunk * EPC) * ES);
+    unsigned msk = 0;
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int dy = P.tapdy[cls][t], dx = P.tapdx[cls][t];
+      const bool ok = mv && (unsigned)(y0 + dy) < (unsigned)p.Hi && (unsigned)(x0 + dx) < (unsigned)p.Wi;
+      msk |= (ok ? 1u : 0u) << t;
+    }
+    vmask[r] = msk;
+  }
+
+  int iss_left = nkt;
+  int iss_t = kbeg / p.cpt, iss_c = kbeg - iss_t * p.cpt;
+  unsigned s_a = 0, s_b = 0;
+  auto tap_switch = [&]() {
+    const int info = P.tapinfo[cls][iss_t];
+    s_a = (unsigned)(((info & 255) * p.Cin + iss_c * BKE) * ES);
+    s_b = (unsigned)(iss_c * 128);
+    const int tapx = (info >> 8) * p.ldx * ES;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cur[r] = ((vmask[r] >> iss_t) & 1u) ? rowoff[r] + (unsigned)tapx : OOB;
+  };
+  auto iss_advance = [&]() {
+    if (iss_left > 1) {
+      --iss_left;
+      s_a += 128; s_b += 128;
+      if (++iss_c == p.cpt) { iss_c = 0; ++iss_t; tap_switch(); }
+    }
+  };
+  tap_switch();
+
+  char *const ldsw = lds + wave * 1024;
+  auto issue_ktile = [&](int stage) {   // compile-time constant at every call site
+    char *dst = ldsw + stage * ST3_BYTES;
+    bload16(wrs, avoff[0], s_a, dst); bload16(wrs, avoff[1], s_a, dst + 8192);
+    bload16(xrs, cur[0], s_b, dst + HT_BYTES); bload16(xrs, cur[1], s_b, dst + HT_BYTES + 8192);
+    bload16(xrs, cur[2], s_b, dst + 2 * HT_BYTES); bload16(xrs, cur[3], s_b, dst + 2 * HT_BYTES + 8192);
+    iss_advance();
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int laneoff = fr * 128 + ((fq ^ (fr & 7)) << 4);
+  const char *ard[2], *brd[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    ard[s] = lds + ((wr * 64 * 128 + laneoff) ^ (s << 6));
+    brd[s] = lds + HT_BYTES + (wc >> 1) * HT_BYTES + (((wc & 1) * 64 * 128 + laneoff) ^ (s << 6));
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue_ktile(0);
+  issue_ktile(1);
+  wait_vmcnt<6>();   // K tile 0 landed
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+
+  frag_t a[4][2], b[4][2];
+#define CFD_KT3(ST)                                                                    \
+    {                                                                                  \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
+          a[i][s] = *(const frag_t *)(ard[s] + ST * ST3_BYTES + i * 2048);             \
+          b[i][s] = *(const frag_t *)(brd[s] + ST * ST3_BYTES + i * 2048);             \
+        }                                                                              \
+      }                                                                                \
+      issue_ktile((ST + 2) % 3);                                                       \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+      wait_vmcnt<6>();                                                                 \
+      __builtin_amdgcn_s_barrier();                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                               \
+      __builtin_amdgcn_s_setprio(1);                                                   \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                \
+            acc[i][j] = mma(a[i][s], b[j][s], acc[i][j]);                              \
+      __builtin_amdgcn_s_setprio(0);                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                               \
+      __builtin_amdgcn_s_barrier();                                                    \
+    }
+  int k = 0;
+  for (; k + 2 < nkt; k += 3) {
+    CFD_KT3(0)
+    CFD_KT3(1)
+    CFD_KT3(2)
+  }
+  if (k < nkt) {
+    CFD_KT3(0)
+    if (k + 1 < nkt) { CFD_KT3(1) }
+  }
+#undef CFD_KT3
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  wait_vmcnt<0>();
+
+  if (p.stat_sum) {
+    __syncthreads();
+    float *part = (float *)lds;   // [2][4 wc][128 n]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nl = wr * 64 + i * 16 + fq * 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[i][j][r] + bv[r];
+          t1 += v;
+          t2 = fmaf(v, v, t2);
+        }
+        t1 = row16_sum(t1);
+        t2 = row16_sum(t2);
+        if (fr == 0) {
+          part[(0 * 4 + wc) * 128 + nl + r] = t1;
+          part[(1 * 4 + wc) * 128 + nl + r] = t2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int which = tid >> 7, c = tid & 127;
+      const float *pp = part + which * 512 + c;
+      const float tot = pp[0] + pp[128] + pp[256] + pp[384];
+      const int b = m0 / (p.Hq * p.Wq);
+      atomicAdd((which ? p.stat_sq : p.stat_sum) + (size_t)b * p.Cout + n0 + c, tot);
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wc * 64 + j * 16 + fr;
+    if (m >= p.M) continue;
+    const int b = m / (p.Hq * p.Wq);
+    const int rem = m - b * (p.Hq * p.Wq);
+    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    int64_t opix;
+    if (p.kind == CFD_CONVT_K4S2)
+      opix = ((int64_t)b * p.Ho + 2 * qy + ph) * p.Wo + 2 * qx + pw;
+    else
+      opix = m;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wr * 64 + i * 16 + fq * 4;
+      f32x4 v = acc[i][j];
+      if (p.split_k > 1) {
+        *(f32x4 *)(p.ws + ((int64_t)sk * p.B * p.Ho * p.Wo + opix) * p.Cout + n) = v;
+        continue;
+      }
+      if (p.bias) v += *(const f32x4 *)(p.bias + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.slope);
+      if (p.out_bf16) {
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;
+      } else {
+        *(f32x4 *)(p.y + (opix * p.ldy + n) * 4) = v;
+      }
+    }
+  }
+}
+
 static int64_t x_bytes(const IgemmParams &p, int es) { return (((int64_t)p.B * p.Hi * p.Wi - 1) * p.ldx + p.Cin) * es; }
 static int64_t w_bytes(const IgemmParams &p, int es) { return (int64_t)p.Cout * p.Kw * es; }
 
 bool igemm256_eligible(const IgemmParams &p, int dtype) {
   const int es = dtype == CFD_BF16 ? 2 : 4;
-  return p.Cout % 256 == 0 && p.Cin % (128 / es) == 0 && p.ntaps <= 16 && x_bytes(p, es) < (1LL << 31) &&
+  return p.Cout % 128 == 0 && p.Cin % (128 / es) == 0 && p.ntaps <= 16 && x_bytes(p, es) < (1LL << 31) &&
          w_bytes(p, es) < (1LL << 31);
 }
 
+// n-tile of the variant that runs this layer: 256 when Cout allows it, else the 128 x 256 variant
+int igemm256_ntile(const IgemmParams &p) { return p.Cout % 256 == 0 ? 256 : 128; }
+
 int igemm256_block_count(const IgemmParams &p) {
-  return cdiv(p.M, 256) * (p.Cout / 256) * p.nclass * p.split_k;
+  return cdiv(p.M, 256) * (p.Cout / igemm256_ntile(p)) * p.nclass * p.split_k;
 }
 
 int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
@@ -423,7 +654,8 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   P.g = pin;
   IgemmParams &p = P.g;
   p.mtiles = cdiv(p.M, 256);
-  p.ntiles = p.Cout / 256;
+  const int ntile = igemm256_ntile(p);
+  p.ntiles = p.Cout / ntile;
   p.nblocks = p.mtiles * p.ntiles * p.nclass * p.split_k;
   P.xbytes = (unsigned)x_bytes(p, es);
   P.wbytes = (unsigned)w_bytes(p, es);
@@ -449,7 +681,17 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
     }                                                                                                               \
     hipLaunchKernelGGL((igemm256_kernel<__VA_ARGS__>), dim3(p.nblocks), dim3(512), shmem, st, P);                   \
   } while (0)
-  if (dtype == CFD_F32) CFD_LAUNCH256(float, 6, false, 4);
+  if (ntile == 128) {
+    const size_t shmem3 = 3 * ST3_BYTES;
+    static bool done3 = false;
+    if (!done3) {
+      CFD_HIP(hipFuncSetAttribute((const void *)igemm128n_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem3));
+      CFD_HIP(hipFuncSetAttribute((const void *)igemm128n_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem3));
+      done3 = true;
+    }
+    if (dtype == CFD_F32) hipLaunchKernelGGL(igemm128n_kernel<float>, dim3(p.nblocks), dim3(512), shmem3, st, P);
+    else hipLaunchKernelGGL(igemm128n_kernel<bf16>, dim3(p.nblocks), dim3(512), shmem3, st, P);
+  } else if (dtype == CFD_F32) CFD_LAUNCH256(float, 6, false, 4);
   else if (pdt == 126) CFD_LAUNCH256(bf16, 6, true, 2);
   else if (pdt == 106) CFD_LAUNCH256(bf16, 6, true, 4);
   else if (pdt == 5) CFD_LAUNCH256(bf16, 5, false, 4);

@@ -85,6 +85,10 @@ def test_conv_forward(kind, B, H, W, cin, cout, dtype):
     ("convT", 2, 8, 24, 128, 256, 1),     # four parity classes, ragged tiles (M = 384)
     ("convT", 1, 1, 8, 64, 256, 2),       # 1x8 input, split-K
     ("dense", 5, 1, 1, 1024, 256, 1),     # dense, M = 5
+    ("convT", 2, 8, 24, 128, 128, 1),     # Cout = 128: the 128 x 256 variant (three-stage ring), 5 K tiles... per class 8
+    ("k4s2", 3, 12, 20, 64, 384, 1),      # Cout = 384 -> three 128-wide n tiles, ragged m tile, 16 K tiles
+    ("k3s1", 2, 16, 32, 64, 128, 2),      # 9 K tiles split in two (5 + 4: both ring tails)
+    ("k4s1", 1, 4, 32, 64, 128, 16),      # one K tile per slice
 ])
 def test_conv_forward_igemm256(kind, B, H, W, cin, cout, split_k, dtype, pd):
     """the 256x256 ping-pong kernel (igemm256.hip; bf16 and exact-f32 MFMA), forced on, against the oracle; bias +
@@ -224,6 +228,7 @@ def test_bn_act(B, H, W, C, drop, dtype):
     ("k4s2", 3, 32, 32, 64, 256, False),    # 256 output pixels per sample: one tile per sample
     ("k4s2", 2, 32, 64, 64, 256, False),    # 512 per sample
     ("convT", 2, 16, 16, 64, 256, True),    # class grid 256 per sample, dropout (RNG mode)
+    ("k4s2", 2, 32, 32, 64, 128, False),    # Cout = 128: 128-wide n tile in both kernels
 ])
 def test_conv_stats_bn_apply(kind, B, H, W, cin, cout, drop, dtype, force256):
     """BatchNorm statistics fused into the conv epilogue + bn_apply == conv -> oracle BatchNorm (+dropout, acts)"""
