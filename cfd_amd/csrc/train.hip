@@ -750,7 +750,9 @@ extern "C" int cfd_conv_first_wgrad(const float *x, const float *x2, int cin1, i
   hipStream_t st = (hipStream_t)stream;
   const int Ho = Hi / stride, Wo = Wi / stride;
   const int64_t npix = (int64_t)B * Ho * Wo;
-  int64_t ppb = (npix + 255) / 256;
+  // ~2048 blocks: eight resident blocks per CU hide the dependent patch / dpre loads of the 8-pixel steps; each block
+  // ends with one contiguous 4-32 KB atomic burst, so the extra blocks cost a few tens of MB of atomics at most
+  int64_t ppb = (npix + 2047) / 2048;
   if (ppb < 64) ppb = 64;
   ppb = (ppb + 7) / 8 * 8;
   const int blocks = (int)((npix + ppb - 1) / ppb);

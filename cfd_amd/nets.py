@@ -179,10 +179,13 @@ class Generator(_Net):
         return ops.convT_out(g, P.c("out.kernel"), P.m("out.bias"), apply_sigmoid=True, want_logits=want_logits)
 
     def backward(self, dz: torch.Tensor, x: torch.Tensor, masks: Optional[List[torch.Tensor]] = None, seed: int = 0,
-                 sample0: int = 0) -> None:
+                 sample0: int = 0, ready=None) -> None:
         """Backward of the forward that JUST ran with the same (x, masks, seed, sample0): dz = dL/dlogits fp32
         (B,H,W,1).  Writes every trainable gradient of the generator into params.grad (bias gradients of
-        convolutions followed by BatchNorm are identically zero and stay at the zero the step memset wrote)."""
+        convolutions followed by BatchNorm are identically zero and stay at the zero the step memset wrote).
+        `ready(layer)` (optional) is called as soon as a layer's kernel and bias gradients are complete, last layer
+        first: the data-parallel trainer starts the all-reduce of that part of the flat buffer there."""
+        ready = ready or (lambda _name: None)
         P, a, B = self.params, self.a, x.shape[0]
         pl = self.plan(B)
         enc, dec = a["enc"], a["dec"]
@@ -195,6 +198,7 @@ class Generator(_Net):
         ops.tap_scatter_grad(dz, dtaps, B, h5, w5, 0)
         ops.tap_dw(dtaps, cat5, P.g("out.kernel"), 16)
         ops.colsum(dz.view(-1, 1), P.g("out.bias"))
+        ready("out")
         dcat = self.buf(pl, "dcat5", cat5.shape)
         ops.tap_dx(dtaps, P.c("out.kernel"), dcat, 16)
         # ---- decoder, last block first
@@ -218,6 +222,7 @@ class Generator(_Net):
                            drop_mask=mask, drop_rate=rate, drop_seed=seed * 16 + i, sample0=sample0, eps=BN_EPS)
             g_in = pl[f"cat{i - 1}"] if i > 1 else pl["b"]
             ops.conv_wgrad(g_in, draw, CONVT_K4S2, f, P.g(f"d{i}.kernel"))
+            ready(f"d{i}")
             dnext = self.buf(pl, f"dcat{i - 1}" if i > 1 else "db", g_in.shape)
             ops.conv_forward(draw, P.t(f"d{i}.kernel"), None, CONV_K4S2, g_in.shape[-1], out=dnext)
             dcat = dnext
@@ -228,6 +233,7 @@ class Generator(_Net):
         e5 = pl["e5"]
         ops.conv_wgrad(e5, dpre, CONV_K4S2, a["bott"], P.g("b.kernel"))
         ops.colsum(dpre, P.g("b.bias"))
+        ready("b")
         de = self.buf(pl, "de5", e5.shape)
         ops.conv_forward(dpre, P.t("b.kernel"), None, CONVT_K4S2, e5.shape[-1], out=de)
         # ---- encoder, deepest first: gradient arrives through the next conv (LeakyReLU) and the skip (ReLU)
@@ -240,12 +246,14 @@ class Generator(_Net):
                            g2=skip_grads[i], act2=ACT_RELU, eps=BN_EPS)
             e_prev = pl[f"e{i - 1}"]
             ops.conv_wgrad(e_prev, draw, CONV_K4S2, f, P.g(f"e{i}.kernel"))
+            ready(f"e{i}")
             de = self.buf(pl, f"de{i - 1}", e_prev.shape)
             ops.conv_forward(draw, P.t(f"e{i}.kernel"), None, CONVT_K4S2, e_prev.shape[-1], out=de)
         e1 = pl["e1"]
         dpre1 = self.buf(pl, "dpre_e1", e1.shape)
         ops.act_bwd(e1, de, ACT_LEAKY, dpre1, g2=skip_grads[1], act2=ACT_RELU)
         ops.conv_first_wgrad(x, None, dpre1, P.g("e1.kernel"), P.g("e1.bias"), 4, 2)
+        ready("e1")
 
 
 class Discriminator(_Net):

@@ -82,6 +82,39 @@ class _DP:
         return 1.0 / self.world
 
 
+class BackwardBuckets:
+    """Overlap of the gradient all-reduce with the backward pass.  The main range [0, n_main) of the flat
+    gradient buffer holds kernels and biases in layer order (e1 .. out) and the backward runs last layer first, so
+    when layer L reports ready everything in [offset(L.kernel), hi) is final: that tail is handed to RCCL on the side
+    stream (once it holds at least `min_elems`, to keep collectives large) while the earlier layers' gradient
+    kernels keep running.  `finish()` sends what is left plus the BatchNorm range."""
+
+    def __init__(self, dp: _DP, params, min_elems: int = 8 * 1024 * 1024):
+        self.dp, self.p, self.min = dp, params, min_elems
+        self.hi = params.n_main
+        self.sent: List[tuple] = []          # (lo, hi) ranges handed to the collective, for tests
+
+    def ready(self, layer: str) -> None:
+        if self.dp.world == 1:
+            return
+        lo = self.p.specs[layer + ".kernel"].offset
+        if self.hi - lo >= self.min or lo == 0:
+            self._send(lo, self.hi)
+            self.hi = lo
+
+    def _send(self, lo: int, hi: int) -> None:
+        if hi > lo:
+            self.dp.reduce_async(self.p.grad[lo:hi])
+            self.sent.append((lo, hi))
+
+    def finish(self) -> None:
+        if self.dp.world == 1:
+            return
+        self._send(0, self.hi)
+        self.hi = 0
+        self._send(self.p.n_main, self.p.n_trainable)
+
+
 class DiscriminatorTrainer:
     def __init__(self, d: nets.Discriminator, lr: float = 2e-3, beta_1: float = 0.5, train_convs: bool = True):
         self.d = d
@@ -151,8 +184,9 @@ class GanTrainer:
         dz = g.buf(g.plan(B), "dz", fake.shape, torch.float32)
         ops.field_loss(fake, tgt, self.field_loss, self.losses[1:2], dz, weight=self.field_weight, dy_extra=dfake,
                        sigmoid_grad=True)
-        g.backward(dz, src, masks=masks, seed=seed, sample0=sample0)
-        self.dp.reduce_async(g.params.grad)
+        buckets = BackwardBuckets(self.dp, g.params)
+        g.backward(dz, src, masks=masks, seed=seed, sample0=sample0, ready=buckets.ready)
+        buckets.finish()
         self.dp.wait()
         self.opt_g.step(self.dp.grad_scale)
         self.opt_dbn.step(self.dp.grad_scale)

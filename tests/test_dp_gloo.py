@@ -27,6 +27,25 @@ def _worker(rank, world, port, out):
     dp.wait()
     expect = torch.arange(4096, dtype=torch.float32) * sum(r + 1 for r in range(world))
     ok = torch.equal(g, expect) and abs(dp.grad_scale - 1.0 / world) < 1e-12
+    # backward-overlap buckets: ranges handed over tail first, disjoint, covering the trainable prefix exactly once
+    class _Spec:
+        def __init__(self, offset):
+            self.offset = offset
+
+    class _P:
+        n_main, n_trainable = 6000, 6400
+        specs = {"e1.kernel": _Spec(0), "e2.kernel": _Spec(1024), "d1.kernel": _Spec(3000), "out.kernel": _Spec(5500)}
+        grad = torch.ones(6400, dtype=torch.float32) * (rank + 1)
+    bk = trainer.BackwardBuckets(dp, _P, min_elems=2000)
+    for layer in ("out", "d1", "e2", "e1"):
+        bk.ready(layer)
+    bk.finish()
+    dp.wait()
+    tot = float(sum(r + 1 for r in range(world)))
+    spans = sorted(bk.sent)
+    ok = ok and spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans[:-2], spans[1:-1])) \
+        and spans[-2][1] == 6000 and spans[-1] == (6000, 6400) and bk.sent[0] == (3000, 6000) \
+        and bool((_P.grad == tot).all())
     lo, hi = sharding.case_range(10001, rank, world)
     out.put((rank, ok, lo, hi))
     dist.destroy_process_group()
