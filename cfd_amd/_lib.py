@@ -60,6 +60,8 @@ SIGNATURES = {
     "cfd_colsum": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp]),
     "cfd_bn_act_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _f, C.c_uint64, _i64, _vp, _i, _vp,
                             _vp, _i, _i, _i, _f, _i, _i, _f, _i, _vp]),
+    "cfd_bn_act_bwd_ws": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _f, C.c_uint64, _i64, _vp, _i, _vp,
+                               _vp, _i, _i, _i, _f, _i, _i, _f, _i, _vp, _vp]),
     "cfd_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _i, _f, _i, _vp]),
     "cfd_maxpool2_act_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "cfd_dropout_apply": (_i, [_vp, _vp, _vp, _i64, _f, C.c_uint64, _i64, _i, _vp]),

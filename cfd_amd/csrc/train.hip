@@ -166,6 +166,120 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same backward for LARGE tensors, split over pixels so that it fills the chip and reads whole pixel rows
+// (block = (sample, chunk of pixels), thread = fixed 8-channel vector, as bn_apply_kernel):
+//   pass 1 (PASS == 1): per-block partial sums of u and u*xhat -> LDS reduce -> contiguous atomics into
+//                       sums[0][b][c], sums[1][b][c] (zeroed by the caller)
+//   pass 2 (PASS == 2): dx from the finished sums; the chunk-0 block of every sample adds them to dbeta / dgamma
+// ---------------------------------------------------------------------------------------------
+template <typename TI, typename TG, int PASS>
+__global__ __launch_bounds__(256) void bn_act_bwd_split_kernel(
+    const TI *__restrict__ x, int ldx, const float *__restrict__ mean, const float *__restrict__ var,
+    const float *__restrict__ gamma, const float *__restrict__ beta, const TG *__restrict__ g1, int ldg1,
+    const TG *__restrict__ g2, int ldg2, const uint8_t *__restrict__ mask, float drop_scale, unsigned drop_thr,
+    uint64_t drop_seed, int64_t sample0, TG *__restrict__ dx, int lddx, float *__restrict__ dgamma,
+    float *__restrict__ dbeta, float *__restrict__ sums, int B, int HW, int C, float eps, int act1, int act2,
+    float slope, int chunks, int pix_per_chunk) {
+  constexpr int VN = 8;
+  __shared__ float red[2][256 * 8];
+  const int CV = C >> 3, rpar = 256 / CV;
+  const int cv = (threadIdx.x % CV) * 8, rl = threadIdx.x / CV;
+  const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+  float mu[VN], rs[VN], ga[VN], be[VN], vv[VN];
+  IO8<float>::load(mean + (size_t)b * C + cv, mu);
+  IO8<float>::load(var + (size_t)b * C + cv, vv);
+  IO8<float>::load(gamma + cv, ga);
+  IO8<float>::load(beta + cv, be);
+#pragma unroll
+  for (int i = 0; i < VN; ++i) rs[i] = rsqrtf(vv[i] + eps);
+  const TI *xb = x + (size_t)b * HW * ldx + cv;
+  const TG *g1b = g1 + (size_t)b * HW * ldg1 + cv;
+  const TG *g2b = g2 ? g2 + (size_t)b * HW * ldg2 + cv : nullptr;
+  const uint8_t *mb = mask ? mask + (size_t)b * HW * C + cv : nullptr;
+
+  auto compute_u = [&](int p, float (&xh)[VN], float (&u)[VN]) {
+    float xv[VN], gv[VN];
+    IO8<TI>::load(xb + (size_t)p * ldx, xv);
+    IO8<TG>::load(g1b + (size_t)p * ldg1, gv);
+    float keep[VN];
+#pragma unroll
+    for (int i = 0; i < VN; ++i) keep[i] = 1.f;
+    if (mb) {
+      const uint8_t *mp = mb + (size_t)p * C;
+#pragma unroll
+      for (int i = 0; i < VN; ++i) keep[i] = mp[i] ? drop_scale : 0.f;
+    } else if (drop_thr) {
+      const uint64_t e0 = ((uint64_t)(sample0 + b) * HW + p) * C + cv;
+      const uint64_t h = dropout_hash2(drop_seed, e0 >> 3);
+#pragma unroll
+      for (int i = 0; i < VN; ++i) keep[i] = (((h >> (8 * i)) & 0xff) >= drop_thr) ? drop_scale : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {
+      xh[i] = (xv[i] - mu[i]) * rs[i];
+      const float bn = fmaf(xh[i], ga[i], be[i]);
+      u[i] = gv[i] * act_grad(bn, act1, slope) * keep[i];
+    }
+    if (g2b) {
+      float g2v[VN];
+      IO8<TG>::load(g2b + (size_t)p * ldg2, g2v);
+#pragma unroll
+      for (int i = 0; i < VN; ++i) {
+        const float bn = fmaf(xh[i], ga[i], be[i]);
+        u[i] = fmaf(g2v[i], act_grad(bn, act2, slope), u[i]);
+      }
+    }
+  };
+
+  const int p0 = chunk * pix_per_chunk;
+  const int p1 = p0 + pix_per_chunk < HW ? p0 + pix_per_chunk : HW;
+  float *s1g = sums + (size_t)b * C, *s2g = sums + (size_t)B * C + (size_t)b * C;
+  if constexpr (PASS == 1) {
+    float s1[VN], s2[VN];
+#pragma unroll
+    for (int i = 0; i < VN; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    for (int p = p0 + rl; p < p1; p += rpar) {
+      float xh[VN], u[VN];
+      compute_u(p, xh, u);
+#pragma unroll
+      for (int i = 0; i < VN; ++i) { s1[i] += u[i]; s2[i] = fmaf(u[i], xh[i], s2[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < VN; ++i) { red[0][rl * C + cv + i] = s1[i]; red[1][rl * C + cv + i] = s2[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float a = 0.f, q = 0.f;
+      for (int k = 0; k < rpar; ++k) { a += red[0][k * C + c]; q += red[1][k * C + c]; }
+      atomicAdd(s1g + c, a);
+      atomicAdd(s2g + c, q);
+    }
+  } else {
+    float t1[VN], t2[VN], m1[VN], m2[VN];
+    IO8<float>::load(s1g + cv, t1);
+    IO8<float>::load(s2g + cv, t2);
+    const float inv_n = 1.f / (float)HW;
+#pragma unroll
+    for (int i = 0; i < VN; ++i) { m1[i] = t1[i] * inv_n; m2[i] = t2[i] * inv_n; }
+    if (chunk == 0 && rl == 0) {
+#pragma unroll
+      for (int i = 0; i < VN; ++i) {
+        if (dbeta) atomicAdd(dbeta + cv + i, t1[i]);
+        if (dgamma) atomicAdd(dgamma + cv + i, t2[i]);
+      }
+    }
+    if (!dx) return;
+    TG *dxb = dx + (size_t)b * HW * lddx + cv;
+    for (int p = p0 + rl; p < p1; p += rpar) {
+      float xh[VN], u[VN], o[VN];
+      compute_u(p, xh, u);
+#pragma unroll
+      for (int i = 0; i < VN; ++i) o[i] = ga[i] * rs[i] * (u[i] - m1[i] - xh[i] * m2[i]);
+      IO8<TG>::store(dxb + (size_t)p * lddx, o);
+    }
+  }
+}
+
 // dpre = g1*act1'(y) + g2*act2'(y), the sign taken from the saved activation y (LeakyReLU/ReLU keep it)
 template <typename T>
 __global__ void act_bwd_kernel(const T *__restrict__ y, int ldy, const T *__restrict__ g1, int ldg1,
@@ -549,11 +663,11 @@ static inline unsigned drop_threshold2(float rate) { return (unsigned)(rate * 25
 
 using namespace cfd;
 
-extern "C" int cfd_bn_act_bwd(const void *x, int ldx, int x_dtype, const float *mean, const float *var,
+static int bn_act_bwd_impl(const void *x, int ldx, int x_dtype, const float *mean, const float *var,
                               const float *gamma, const float *beta, const void *g1, int ldg1, const void *g2,
                               int ldg2, const uint8_t *drop_mask, float drop_rate, uint64_t drop_seed,
                               int64_t sample0, void *dx, int lddx, float *dgamma, float *dbeta, int B, int HW, int C,
-                              float eps, int act1, int act2, float slope, int dtype, void *stream) {
+                              float eps, int act1, int act2, float slope, int dtype, float *sums, void *stream) {
   CFD_REQUIRE(x && mean && var && gamma && beta && g1, "NULL pointer");
   CFD_REQUIRE(dtype == CFD_BF16 || dtype == CFD_F32, "bad dtype");
   CFD_REQUIRE(x_dtype == CFD_F32 || (x_dtype == CFD_BF16 && dtype == CFD_BF16), "bad x_dtype/dtype combination");
@@ -562,8 +676,26 @@ extern "C" int cfd_bn_act_bwd(const void *x, int ldx, int x_dtype, const float *
   CFD_REQUIRE(drop_rate >= 0.f && drop_rate < 1.f, "drop_rate must be in [0,1)");
   const float drop_scale = 1.f / (1.f - drop_rate);
   const unsigned thr = (drop_mask || drop_rate == 0.f) ? 0u : drop_threshold2(drop_rate);
-  const int blocks = B * ((C + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
+  // large tensors with a sums workspace: two coalesced, chip-filling passes
+  if (sums && C >= 64 && C / 8 <= 256 && 256 % (C / 8) == 0 && (int64_t)B * HW * C >= (1 << 22)) {
+    const int rpar = 256 / (C / 8);
+    int ppc = rpar * 16;
+    if (ppc > HW) ppc = HW;
+    const int chunks = (HW + ppc - 1) / ppc;
+#define BWD2(TI, TG, PASS)                                                                                           \
+  hipLaunchKernelGGL((bn_act_bwd_split_kernel<TI, TG, PASS>), dim3(B * chunks), dim3(256), 0, st, (const TI *)x, ldx, \
+                     mean, var, gamma, beta, (const TG *)g1, ldg1, (const TG *)g2, ldg2, drop_mask, drop_scale, thr, \
+                     drop_seed, sample0, (TG *)dx, lddx, dgamma, dbeta, sums, B, HW, C, eps, act1, act2, slope,      \
+                     chunks, ppc)
+    if (dtype == CFD_BF16 && x_dtype == CFD_BF16) { BWD2(bf16, bf16, 1); BWD2(bf16, bf16, 2); }
+    else if (dtype == CFD_BF16) { BWD2(float, bf16, 1); BWD2(float, bf16, 2); }
+    else { BWD2(float, float, 1); BWD2(float, float, 2); }
+#undef BWD2
+    CFD_LAUNCH_CHECK();
+    return CFD_OK;
+  }
+  const int blocks = B * ((C + 63) / 64);
 #define BWD(TI, TG)                                                                                                  \
   hipLaunchKernelGGL((bn_act_bwd_kernel<TI, TG>), dim3(blocks), dim3(256), 0, st, (const TI *)x, ldx, mean, var,     \
                      gamma, beta, (const TG *)g1, ldg1, (const TG *)g2, ldg2, drop_mask, drop_scale, thr, drop_seed, \
@@ -574,6 +706,24 @@ extern "C" int cfd_bn_act_bwd(const void *x, int ldx, int x_dtype, const float *
 #undef BWD
   CFD_LAUNCH_CHECK();
   return CFD_OK;
+}
+
+extern "C" int cfd_bn_act_bwd(const void *x, int ldx, int x_dtype, const float *mean, const float *var,
+                              const float *gamma, const float *beta, const void *g1, int ldg1, const void *g2,
+                              int ldg2, const uint8_t *drop_mask, float drop_rate, uint64_t drop_seed,
+                              int64_t sample0, void *dx, int lddx, float *dgamma, float *dbeta, int B, int HW, int C,
+                              float eps, int act1, int act2, float slope, int dtype, void *stream) {
+  return bn_act_bwd_impl(x, ldx, x_dtype, mean, var, gamma, beta, g1, ldg1, g2, ldg2, drop_mask, drop_rate, drop_seed,
+                         sample0, dx, lddx, dgamma, dbeta, B, HW, C, eps, act1, act2, slope, dtype, nullptr, stream);
+}
+
+extern "C" int cfd_bn_act_bwd_ws(const void *x, int ldx, int x_dtype, const float *mean, const float *var,
+                                 const float *gamma, const float *beta, const void *g1, int ldg1, const void *g2,
+                                 int ldg2, const uint8_t *drop_mask, float drop_rate, uint64_t drop_seed,
+                                 int64_t sample0, void *dx, int lddx, float *dgamma, float *dbeta, int B, int HW, int C,
+                                 float eps, int act1, int act2, float slope, int dtype, float *sums, void *stream) {
+  return bn_act_bwd_impl(x, ldx, x_dtype, mean, var, gamma, beta, g1, ldg1, g2, ldg2, drop_mask, drop_rate, drop_seed,
+                         sample0, dx, lddx, dgamma, dbeta, B, HW, C, eps, act1, act2, slope, dtype, sums, stream);
 }
 
 extern "C" int cfd_act_bwd(const void *y, int ldy, const void *g1, int ldg1, const void *g2, int ldg2, void *dx,

@@ -70,13 +70,20 @@ class _Net:
         if buf is None:
             tot = sum(2 * B * f for _n, f in self.bn_layers)
             buf = pl["bn_stats"] = torch.empty(tot, dtype=torch.float32, device=self.device)
-            off, views = 0, {}
+            off, views, flat = 0, {}, {}
             for n, f in self.bn_layers:
                 views[n] = (buf[off:off + B * f].view(B, f), buf[off + B * f:off + 2 * B * f].view(B, f))
+                flat[n] = buf[off:off + 2 * B * f]
                 off += 2 * B * f
-            pl["bn_stats_views"] = views
+            pl["bn_stats_views"], pl["bn_stats_flat"] = views, flat
         buf.zero_()
         return pl["bn_stats_views"]
+
+    def bn_bwd_sums(self, pl: dict, B: int) -> dict:
+        """the same flat buffer, zeroed again, as the (2, B, C) partial-sum scratch of the BatchNorm backward (the
+        forward statistics are already condensed into mean / var by then)"""
+        self.bn_stats(pl, B)
+        return pl["bn_stats_flat"]
 
     def conv_bn(self, pl: dict, st: dict, name: str, x: torch.Tensor, kind: int, f: int, raw: torch.Tensor, act: int,
                 out: torch.Tensor, **kw) -> None:
@@ -188,6 +195,7 @@ class Generator(_Net):
         ready = ready or (lambda _name: None)
         P, a, B = self.params, self.a, x.shape[0]
         pl = self.plan(B)
+        sums = self.bn_bwd_sums(pl, B)
         enc, dec = a["enc"], a["dec"]
         skips = enc[::-1]
         dt = self.dtype
@@ -219,7 +227,8 @@ class Generator(_Net):
             draw = self.buf(pl, f"draw_d{i}", raw.shape)
             ops.bn_act_bwd(raw, pl[f"mean_d{i}"], pl[f"var_d{i}"], P.m(f"d{i}.bn.gamma"), P.m(f"d{i}.bn.beta"),
                            dcat[..., :f], ACT_RELU, draw, P.g(f"d{i}.bn.gamma"), P.g(f"d{i}.bn.beta"),
-                           drop_mask=mask, drop_rate=rate, drop_seed=seed * 16 + i, sample0=sample0, eps=BN_EPS)
+                           drop_mask=mask, drop_rate=rate, drop_seed=seed * 16 + i, sample0=sample0, eps=BN_EPS,
+                           sums=sums[f"d{i}"])
             g_in = pl[f"cat{i - 1}"] if i > 1 else pl["b"]
             ops.conv_wgrad(g_in, draw, CONVT_K4S2, f, P.g(f"d{i}.kernel"))
             ready(f"d{i}")
@@ -243,7 +252,7 @@ class Generator(_Net):
             draw = self.buf(pl, f"draw_e{i}", raw.shape)
             ops.bn_act_bwd(raw, pl[f"mean_e{i}"], pl[f"var_e{i}"], P.m(f"e{i}.bn.gamma"), P.m(f"e{i}.bn.beta"),
                            de, ACT_LEAKY, draw, P.g(f"e{i}.bn.gamma"), P.g(f"e{i}.bn.beta"),
-                           g2=skip_grads[i], act2=ACT_RELU, eps=BN_EPS)
+                           g2=skip_grads[i], act2=ACT_RELU, eps=BN_EPS, sums=sums[f"e{i}"])
             e_prev = pl[f"e{i - 1}"]
             ops.conv_wgrad(e_prev, draw, CONV_K4S2, f, P.g(f"e{i}.kernel"))
             ready(f"e{i}")
@@ -318,6 +327,7 @@ class Discriminator(_Net):
         gradient w.r.t. the target image (the generator's output) is returned as fp32 (B,H,W,1)."""
         P, B = self.params, src.shape[0]
         pl = self.plan(B)
+        sums = self.bn_bwd_sums(pl, B)
         c5 = pl["c5"]
         _, h, w, cc = c5.shape
         dtaps = self.buf(pl, "dtaps", (B * h * w, 16), torch.float32)
@@ -332,7 +342,8 @@ class Discriminator(_Net):
             raw = pl[f"raw_c{i}"]
             draw = self.buf(pl, f"draw_c{i}", raw.shape)
             ops.bn_act_bwd(raw, pl[f"mean_c{i}"], pl[f"var_c{i}"], P.m(f"c{i}.bn.gamma"), P.m(f"c{i}.bn.beta"),
-                           dc, ACT_LEAKY, draw, P.g(f"c{i}.bn.gamma"), P.g(f"c{i}.bn.beta"), eps=BN_EPS)
+                           dc, ACT_LEAKY, draw, P.g(f"c{i}.bn.gamma"), P.g(f"c{i}.bn.beta"), eps=BN_EPS,
+                           sums=sums[f"c{i}"])
             prev = pl[f"c{i - 1}"]
             kind = CONV_K4S2 if s == 2 else CONV_K4S1
             if train_convs:

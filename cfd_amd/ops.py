@@ -404,7 +404,8 @@ def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
 
 
 def bn_act_bwd(x, mean, var, gamma, beta, g1, act1, dx, dgamma, dbeta, g2=None, act2=ACT_RELU, drop_mask=None,
-               drop_rate=0.0, drop_seed=0, sample0=0, eps=1e-3, slope=LEAKY_SLOPE):
+               drop_rate=0.0, drop_seed=0, sample0=0, eps=1e-3, slope=LEAKY_SLOPE, sums=None):
+    """`sums`: optional zeroed fp32 (2, B, C) scratch; large tensors then take the two-pass pixel-parallel path"""
     B, H, W, Cc = x.shape
     xp, ldx = _nhwc(x)
     g1p, ldg1 = _nhwc(g1)
@@ -412,10 +413,12 @@ def bn_act_bwd(x, mean, var, gamma, beta, g1, act1, dx, dgamma, dbeta, g2=None, 
     dxp, lddx = (None, 0) if dx is None else _nhwc(dx)
     if drop_mask is not None and drop_rate == 0.0:
         drop_rate = 0.5
-    check(_lib.load().cfd_bn_act_bwd(xp, ldx, _DT[x.dtype], _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), g1p, ldg1,
-                                     g2p, ldg2, _ptr(drop_mask), drop_rate, drop_seed, sample0, dxp, lddx,
-                                     _ptr(dgamma), _ptr(dbeta), B, H * W, Cc, eps, act1, act2, slope, _DT[g1.dtype],
-                                     _stream()), "cfd_bn_act_bwd")
+    if sums is not None and (sums.numel() < 2 * B * Cc or sums.dtype != torch.float32 or not sums.is_contiguous()):
+        raise _lib.CfdError("sums must be contiguous fp32 with at least 2*B*C elements")
+    check(_lib.load().cfd_bn_act_bwd_ws(xp, ldx, _DT[x.dtype], _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), g1p, ldg1,
+                                        g2p, ldg2, _ptr(drop_mask), drop_rate, drop_seed, sample0, dxp, lddx,
+                                        _ptr(dgamma), _ptr(dbeta), B, H * W, Cc, eps, act1, act2, slope, _DT[g1.dtype],
+                                        _ptr(sums), _stream()), "cfd_bn_act_bwd_ws")
     return dx
 
 

@@ -188,6 +188,13 @@ int cfd_bn_act_bwd(const void *x, int ldx, int x_dtype, const float *mean, const
                    float drop_rate, uint64_t drop_seed, int64_t sample0, void *dx, int lddx, float *dgamma,
                    float *dbeta, int B, int HW, int C, float eps, int act1, int act2, float leaky_slope, int dtype,
                    void *stream);
+/* Same, with scratch: `sums` fp32 [2][B][C], ZEROED by the caller (may be NULL = cfd_bn_act_bwd).  Large tensors
+ * then run as two pixel-parallel, fully coalesced passes (partial sums by atomics into `sums`, then dx). */
+int cfd_bn_act_bwd_ws(const void *x, int ldx, int x_dtype, const float *mean, const float *var, const float *gamma,
+                      const float *beta, const void *g1, int ldg1, const void *g2, int ldg2, const uint8_t *drop_mask,
+                      float drop_rate, uint64_t drop_seed, int64_t sample0, void *dx, int lddx, float *dgamma,
+                      float *dbeta, int B, int HW, int C, float eps, int act1, int act2, float leaky_slope, int dtype,
+                      float *sums, void *stream);
 /* layers without BN: dpre = g1*act1'(y) + g2*act2'(y), y = the saved activation (its sign decides) */
 int cfd_act_bwd(const void *y, int ldy, const void *g1, int ldg1, const void *g2, int ldg2, void *dx, int lddx,
                 int64_t pixels, int C, int act1, int act2, float leaky_slope, int dtype, void *stream);

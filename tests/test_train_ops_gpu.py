@@ -137,7 +137,9 @@ def test_conv_wgrad256(kind, B, H, W, cin, cout, split):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,C,drop,two", [(2, 4, 32, 128, False, True), (3, 2, 16, 64, True, False),
-                                              (1, 16, 64, 64, False, False)])
+                                              (1, 16, 64, 64, False, False),
+                                              (2, 64, 128, 256, True, False),     # large: two-pass pixel-parallel path
+                                              (2, 32, 128, 512, False, True)])
 def test_bn_act_bwd(B, H, W, C, drop, two, dtype):
     from cfd_amd import ops
     dev = "cuda"
@@ -167,7 +169,8 @@ def test_bn_act_bwd(B, H, W, C, drop, two, dtype):
     ops.bn_act_bwd(x.detach().to(dev).to(dtype), mean.to(dev).contiguous(), var.to(dev).contiguous(),
                    gamma.detach().to(dev), beta.detach().to(dev), g1.to(dev).to(dtype), act1, dx, dg, db,
                    g2=None if g2 is None else g2.to(dev).to(dtype), act2=ops.ACT_RELU,
-                   drop_mask=None if mask is None else mask.to(torch.uint8).to(dev))
+                   drop_mask=None if mask is None else mask.to(torch.uint8).to(dev),
+                   sums=torch.zeros(2 * B * C, device=dev))
     assert relerr(dx.float(), x.grad) <= TOL[dtype]
     assert relerr(dg, gamma.grad) <= 1e-4
     assert relerr(db, beta.grad) <= 1e-4
