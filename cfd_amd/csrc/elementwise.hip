@@ -11,8 +11,20 @@
 
 namespace cfd {
 
+// Device-resident dropout epoch: added (times an odd constant) to RNG-mode dropout seeds of the FORWARD kernels whose
+// bit 63 is set (CFD_DROP_SEED_EPOCH_BIT).  A captured HIP graph bakes its kernel arguments, so a graph-replayed
+// predict passes such a seed and advances this word with a one-thread kernel at the head of the graph to get a fresh
+// draw per replay (generator.py:36 keeps Dropout active at inference).  Seeds below 2^63 -- everything a training
+// step uses, whose backward kernels must reproduce the forward mask -- are never touched by the epoch.
+__device__ unsigned long long g_drop_epoch = 0ULL;
+
+__global__ void drop_epoch_kernel(unsigned long long delta, int set) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) g_drop_epoch = set ? delta : g_drop_epoch + delta;
+}
+
 // splitmix64 finaliser over (seed, group index): 8 random bytes, one per element of an aligned group of 8
 __device__ __forceinline__ uint64_t dropout_hash(uint64_t seed, uint64_t group) {
+  if (seed >> 63) seed += g_drop_epoch * 0xD6E8FEB86659FD93ULL;
   uint64_t z = seed + (group + 1) * 0x9E3779B97F4A7C15ULL;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
@@ -296,6 +308,12 @@ __global__ void cast_copy_kernel(const TI *__restrict__ x, int ldx, TO *__restri
 using namespace cfd;
 
 static inline unsigned drop_threshold(float rate) { return (unsigned)(rate * 256.f + 0.5f); }
+
+extern "C" int cfd_dropout_epoch(uint64_t value, int set, void *stream) {
+  hipLaunchKernelGGL(drop_epoch_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)value, set);
+  CFD_LAUNCH_CHECK();
+  return CFD_OK;
+}
 
 extern "C" int cfd_dropout_mask(uint8_t *mask, int64_t sample0, int B, int HW, int C, float rate, uint64_t seed,
                                 void *stream) {

@@ -674,6 +674,8 @@ static int bn_act_bwd_impl(const void *x, int ldx, int x_dtype, const float *mea
   CFD_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldg1 % 8 == 0 && (!g2 || ldg2 % 8 == 0) && (!dx || lddx % 8 == 0),
               "C and strides must be multiples of 8");
   CFD_REQUIRE(drop_rate >= 0.f && drop_rate < 1.f, "drop_rate must be in [0,1)");
+  CFD_REQUIRE(drop_mask || drop_rate == 0.f || !(drop_seed >> 63),
+              "epoch-keyed dropout seeds (bit 63, cfd_dropout_epoch) are forward-only: a backward cannot reproduce them");
   const float drop_scale = 1.f / (1.f - drop_rate);
   const unsigned thr = (drop_mask || drop_rate == 0.f) ? 0u : drop_threshold2(drop_rate);
   hipStream_t st = (hipStream_t)stream;

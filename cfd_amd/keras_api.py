@@ -37,6 +37,34 @@ def _dtype() -> torch.dtype:
         os.environ.get("CFD_AMD_DTYPE", "bf16").lower()]
 
 
+GRAPH_MAX_BATCH = 8     # largest batch whose predict may be replayed as one captured HIP graph (CFD_AMD_GRAPHS=1)
+
+
+class _GraphedForward:
+    """One captured HIP graph of `net.forward` for a fixed batch size: the per-case predict loop of the reference
+    (utils.py:55-58, U/valid.py:25-35) issues ~80 kernels per case.  Measured at batch 1 the replay saves only ~1-3 %
+    (0.79 vs 0.80 ms for U: the small layers are latency-bound on the GPU, not on the host), so it is opt-in.  The
+    graph starts with the dropout-epoch kernel so that every replay draws fresh dropout."""
+
+    def __init__(self, net, x: torch.Tensor, **fwd):
+        self.x = x.clone()
+        net.forward(self.x, **fwd)                     # warm-up: buffers, function attributes, workspace
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            ops.dropout_epoch(1)
+            self.y = net.forward(self.x, **fwd)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        self.x.copy_(x)
+        self.graph.replay()
+        return self.y
+
+
+def _use_graphs() -> bool:
+    return os.environ.get("CFD_AMD_GRAPHS", "0") == "1"
+
+
 def _dev(a) -> torch.Tensor:
     """numpy / list-of-one-numpy (Keras accepts both, utils.py:56) -> fp32 device tensor"""
     if isinstance(a, (list, tuple)):
@@ -80,6 +108,7 @@ class Model:
         self.image_shape = tuple(image_shape)
         self.layers: List[Layer] = []
         self._seed = int.from_bytes(os.urandom(4), "little")   # dropout is random run to run, as in Keras
+        self._graphs = {}                                      # batch size -> _GraphedForward (small-batch predict)
         self.compiled = True
 
     # -- Keras surface ---------------------------------------------------------------------
@@ -121,6 +150,15 @@ class GeneratorModel(Model):
         """BatchNorm and Dropout run in training mode here too (they are built with training=True,
         generator.py:21,33,36): per-sample statistics, fresh dropout draw per call."""
         xd = _dev(x)
+        B = xd.shape[0]
+        if B == 0:
+            return np.zeros((0,) + tuple(self.image_shape), dtype=np.float32)
+        if B <= GRAPH_MAX_BATCH and _use_graphs():
+            g = self._graphs.get(B)
+            if g is None:
+                # bit 59 of the seed -> bit 63 of every layer's drop_seed (seed * 16 + layer): epoch-keyed
+                g = self._graphs[B] = _GraphedForward(self.net, xd, seed=(1 << 59) | (self._next_seed() & ((1 << 59) - 1)))
+            return g(xd).cpu().numpy()
         return self.net.forward(xd, seed=self._next_seed()).cpu().numpy()
 
     __call__ = predict
@@ -222,7 +260,16 @@ class CnnModel(Model):
         return self._trainer
 
     def predict(self, x, verbose=0):
-        return self.net.forward(_dev(x), training=False).cpu().numpy()
+        xd = _dev(x)
+        B = xd.shape[0]
+        if B == 0:
+            return np.zeros((0, 1), dtype=np.float32)
+        if B <= GRAPH_MAX_BATCH and _use_graphs():
+            g = self._graphs.get(B)
+            if g is None:
+                g = self._graphs[B] = _GraphedForward(self.net, xd, training=False)
+            return g(xd).cpu().numpy()
+        return self.net.forward(xd, training=False).cpu().numpy()
 
     def train_on_batch(self, x, y):
         return self._tr().train_on_batch(_dev(x), _dev(y).reshape(-1, 1), seed=self._next_seed())

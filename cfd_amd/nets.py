@@ -99,6 +99,15 @@ class _Net:
         else:
             ops.bn_act(raw, g, b, act, out=out, mean=mean, var=var, eps=BN_EPS, **kw)
 
+    def check_image(self, *imgs: torch.Tensor) -> None:
+        """every image operand must be the fp32 (B, H, W, 1) grid this net was built for: the layer buffers are sized
+        from (H, W) and the kernels do not bounds-check"""
+        B = imgs[0].shape[0]
+        for t in imgs:
+            if tuple(t.shape) != (B, self.H, self.W, 1) or t.dtype != torch.float32 or not t.is_cuda:
+                raise ValueError(f"expected a float32 device tensor of shape ({B}, {self.H}, {self.W}, 1), got "
+                                 f"{tuple(t.shape)} {t.dtype} on {t.device} (build the net with image_shape=...)")
+
     def raw_dtype(self, h: int, w: int, c: int) -> torch.dtype:
         return torch.float32 if (self.dtype == torch.float32 or h * w * c <= RAW_F32_MAX_ELEMS) else self.dtype
 
@@ -140,6 +149,7 @@ class Generator(_Net):
                 want_logits: bool = False, keep: bool = False):
         """x: fp32 (B,H,W,1) device tensor.  Dropout (always active, generator.py:36): explicit uint8
         `masks` (one per dropout layer, parity tests) or the kernel RNG keyed by (seed, sample0)."""
+        self.check_image(x)
         P, a, B = self.params, self.a, x.shape[0]
         pl = self.plan(B)
         enc, dec = a["enc"], a["dec"]
@@ -193,6 +203,7 @@ class Generator(_Net):
         `ready(layer)` (optional) is called as soon as a layer's kernel and bias gradients are complete, last layer
         first: the data-parallel trainer starts the all-reduce of that part of the flat buffer there."""
         ready = ready or (lambda _name: None)
+        self.check_image(x, dz)
         P, a, B = self.params, self.a, x.shape[0]
         pl = self.plan(B)
         sums = self.bn_bwd_sums(pl, B)
@@ -268,6 +279,8 @@ class Generator(_Net):
 class Discriminator(_Net):
     def __init__(self, image_shape=(64, 512, 1), device="cuda", dtype=torch.bfloat16, seed: int = 1):
         self.H, self.W, cin = image_shape
+        if cin != 1 or self.H % 16 or self.W % 16:
+            raise ValueError("discriminator needs a 1-channel image with H and W multiples of 16")
         specs, c = [], 2 * cin
         for i, (f, _s, bn) in enumerate(DISC, 1):
             specs += [Spec(f"c{i}.kernel", "conv", (4, 4, c, f)), Spec(f"c{i}.bias", "vec", (f,))]
@@ -286,6 +299,7 @@ class Discriminator(_Net):
 
     def forward(self, src: torch.Tensor, tgt: torch.Tensor, training: bool, want_logits: bool = False):
         """src, tgt: fp32 (B,H,W,1).  training=True: batch statistics (per sample); False: moving statistics."""
+        self.check_image(src, tgt)
         P, B = self.params, src.shape[0]
         pl = self.plan(B)
         h, w = self.H // 2, self.W // 2
@@ -325,7 +339,10 @@ class Discriminator(_Net):
         """Backward of the training-mode forward that JUST ran on (src, tgt).  train_convs=False is the
         composite-GAN case: only BatchNorm gamma/beta receive gradients (U/models/generator.py:79-81) and the
         gradient w.r.t. the target image (the generator's output) is returned as fp32 (B,H,W,1)."""
+        self.check_image(src, tgt)
         P, B = self.params, src.shape[0]
+        if tuple(dlogits.shape) != (B,) + self.patch_shape:
+            raise ValueError(f"dlogits must be {(B,) + self.patch_shape}, got {tuple(dlogits.shape)}")
         pl = self.plan(B)
         sums = self.bn_bwd_sums(pl, B)
         c5 = pl["c5"]
@@ -383,6 +400,7 @@ class CnnRegressor(_Net):
                 seed: int = 0, sample0: int = 0):
         """x fp32 (B,H,W,1) -> fp32 (B,1).  Dropout(0.5) after fc1 only in training (explicit uint8 (B,256)
         mask, or the kernel RNG keyed by (seed, sample0))."""
+        self.check_image(x)
         P, B = self.params, x.shape[0]
         pl = self.plan(B)
         H, W = self.H, self.W
@@ -414,7 +432,10 @@ class CnnRegressor(_Net):
     def backward(self, dy: torch.Tensor, x: torch.Tensor, drop_mask: Optional[torch.Tensor] = None, seed: int = 0,
                  sample0: int = 0) -> None:
         """Backward of the training forward that JUST ran; dy = dL/dy fp32 (B,1)."""
+        self.check_image(x)
         P, B = self.params, x.shape[0]
+        if tuple(dy.shape) != (B, 1):
+            raise ValueError(f"dy must be ({B}, 1), got {tuple(dy.shape)}")
         pl = self.plan(B)
         dt = self.dtype
         H, W = self.H, self.W

@@ -51,6 +51,21 @@ def _nhwc(t: torch.Tensor) -> Tuple[C.c_void_p, int]:
     return C.c_void_p(t.data_ptr()), ld
 
 
+def _need(cond: bool, what: str) -> None:
+    """Host-side operand check: the kernels index by the sizes they are given and never bounds-check, so every
+    wrapper verifies that each tensor really has the extent its kernel will touch before launching."""
+    if not cond:
+        raise _lib.CfdError("shape check failed: " + what)
+
+
+def _numel(t: Optional[torch.Tensor], n: int, what: str, dtype: Optional[torch.dtype] = None) -> None:
+    if t is None:
+        return
+    _need(t.numel() >= n and t.is_contiguous(), f"{what} needs {n} contiguous elements, has {tuple(t.shape)}")
+    if dtype is not None:
+        _need(t.dtype == dtype, f"{what} must be {dtype}, is {t.dtype}")
+
+
 def conv_out_shape(kind: int, B: int, Hi: int, Wi: int, cout: int):
     if kind == CONV_K4S2:
         return (B, Hi // 2, Wi // 2, cout)
@@ -123,6 +138,13 @@ def conv_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
         shp = (B, cout) if kind == DENSE else conv_out_shape(kind, B, Hi, Wi, cout)
         out = torch.empty(shp, dtype=odt, device=x.device)
     yp, ldy = _nhwc(out)
+    want = (B, cout) if kind == DENSE else conv_out_shape(kind, B, Hi, Wi, cout)
+    _need(tuple(out.shape) == tuple(want), f"conv_forward out is {tuple(out.shape)}, kind {kind} on {tuple(x.shape)} gives {want}")
+    _numel(w, cout * _TAPS[kind] * cin, "conv weight")
+    _numel(bias, cout, "conv bias", torch.float32)
+    if stats is not None:
+        _numel(stats[0], B * cout, "stats sum", torch.float32)
+        _numel(stats[1], B * cout, "stats sumsq", torch.float32)
     d = ConvDesc(kind=kind, dtype=_DT[x.dtype], out_dtype=_DT[out.dtype], B=B, Hi=Hi, Wi=Wi, Cin=cin, Cout=cout,
                  ldx=ldx, ldy=ldy, act=act, leaky_slope=slope, split_k=1)
     if w.dtype != x.dtype:
@@ -191,6 +213,15 @@ def conv_first(x: torch.Tensor, x2: Optional[torch.Tensor], w: torch.Tensor, bia
         out = torch.empty((B, Hi // stride, Wi // stride, cout), dtype=out_dtype, device=x.device)
     yp, ldy = _nhwc(out)
     y2p, ldy2 = (None, 0) if out2 is None else _nhwc(out2)
+    want = (B, Hi // stride, Wi // stride, cout)
+    _need(Hi % stride == 0 and Wi % stride == 0, "conv_first: H, W must be multiples of the stride")
+    _need(x2 is None or (tuple(x2.shape[:3]) == (B, Hi, Wi) and x2.dtype == torch.float32),
+          f"conv_first x2 {None if x2 is None else tuple(x2.shape)} does not match x {tuple(x.shape)}")
+    _need(tuple(out.shape) == want, f"conv_first out is {tuple(out.shape)}, expected {want}")
+    _need(out2 is None or (tuple(out2.shape) == want and out2.dtype == out.dtype),
+          f"conv_first out2 {None if out2 is None else tuple(out2.shape)} != {want}")
+    _numel(w, cout * ksize * ksize * (c1 + c2), "conv_first weight", torch.float32)
+    _numel(bias, cout, "conv_first bias", torch.float32)
     check(_lib.load().cfd_conv_first(_ptr(x), _ptr(x2), c1, c2, _ptr(w), _ptr(bias), yp, ldy, y2p, ldy2, B, Hi, Wi,
                                      cout, ksize, stride, act, act2, slope, _DT[out.dtype], _stream()),
           "cfd_conv_first")
@@ -205,9 +236,20 @@ def convT_out(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], ap
     taps = _workspace(B * Hi * Wi * 16 * 4, x.device)
     y = torch.empty((B, 2 * Hi, 2 * Wi, 1), dtype=torch.float32, device=x.device)
     logits = torch.empty_like(y) if want_logits else None
+    _numel(w, 16 * cin, "convT_out weight", x.dtype)
+    _numel(bias, 1, "convT_out bias", torch.float32)
     check(_lib.load().cfd_convT_out(xp, ldx, _ptr(w), _ptr(bias), _ptr(taps), _ptr(y), _ptr(logits), B, Hi, Wi, cin,
                                     _DT[x.dtype], int(apply_sigmoid), _stream()), "cfd_convT_out")
     return (y, logits) if want_logits else y
+
+
+def _bn_checks(x, out, out2, gamma, beta, drop_mask) -> None:
+    shp, Cc = tuple(x.shape), x.shape[-1]
+    _need(tuple(out.shape) == shp, f"bn out {tuple(out.shape)} != x {shp}")
+    _need(out2 is None or tuple(out2.shape) == shp, f"bn out2 {None if out2 is None else tuple(out2.shape)} != x {shp}")
+    _numel(gamma, Cc, "bn gamma", torch.float32)
+    _numel(beta, Cc, "bn beta", torch.float32)
+    _need(drop_mask is None or tuple(drop_mask.shape) == shp, f"drop_mask shape != x {shp}")
 
 
 def bn_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int, out: Optional[torch.Tensor] = None,
@@ -228,6 +270,10 @@ def bn_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int, o
         raise _lib.CfdError("drop_mask must be dense uint8 NHWC")
     if drop_mask is not None and drop_rate == 0.0:
         drop_rate = 0.5
+    _bn_checks(x, out, out2, gamma, beta, drop_mask)
+    nstat = Cc if use_moving else B * Cc
+    _numel(mean, nstat, "bn mean", torch.float32)
+    _numel(var, nstat, "bn var", torch.float32)
     check(_lib.load().cfd_bn_act(xp, ldx, _DT[x.dtype], _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var),
                                  int(use_moving), _ptr(drop_mask), drop_rate, drop_seed, sample0, yp, ldy, y2p, ldy2,
                                  B, H * W, Cc, eps, act, act2, slope, _DT[out.dtype], _stream()), "cfd_bn_act")
@@ -252,11 +298,19 @@ def bn_apply(x: torch.Tensor, stats: Tuple[torch.Tensor, torch.Tensor], gamma: t
         raise _lib.CfdError("drop_mask must be dense uint8 NHWC")
     if drop_mask is not None and drop_rate == 0.0:
         drop_rate = 0.5
+    _bn_checks(x, out, out2, gamma, beta, drop_mask)
+    for t, what in ((stats[0], "stats sum"), (stats[1], "stats sumsq"), (mean, "bn mean"), (var, "bn var")):
+        _numel(t, B * Cc, what, torch.float32)
     check(_lib.load().cfd_bn_apply(xp, ldx, _DT[x.dtype], _ptr(stats[0]), _ptr(stats[1]), _ptr(gamma), _ptr(beta),
                                    _ptr(mean), _ptr(var), _ptr(drop_mask), drop_rate, drop_seed, sample0, yp, ldy,
                                    y2p, ldy2, B, H * W, Cc, eps, act, act2, slope, _DT[out.dtype], _stream()),
           "cfd_bn_apply")
     return out
+
+
+def dropout_epoch(value: int, set_: bool = False) -> None:
+    """advance (or set) the device-resident dropout epoch on the current stream (see cfd_dropout_epoch)"""
+    check(_lib.load().cfd_dropout_epoch(int(value), int(set_), _stream()), "cfd_dropout_epoch")
 
 
 def dropout_mask(shape, rate: float, seed: int, sample0: int = 0, device="cuda") -> torch.Tensor:
@@ -271,6 +325,7 @@ def maxpool2(x: torch.Tensor) -> torch.Tensor:
     B, H, W, Cc = x.shape
     if not x.is_contiguous():
         raise _lib.CfdError("maxpool2 input must be dense NHWC")
+    _need(H % 2 == 0 and W % 2 == 0, "maxpool2 needs even H and W")
     y = torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
     check(_lib.load().cfd_maxpool2(_ptr(x), _ptr(y), B, H, W, Cc, _DT[x.dtype], _stream()), "cfd_maxpool2")
     return y
@@ -280,6 +335,7 @@ def cast_copy(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     xp, ldx = _nhwc(x)
     yp, ldy = _nhwc(out)
     pixels = x.numel() // x.shape[-1]
+    _need(tuple(out.shape) == tuple(x.shape), f"cast_copy out {tuple(out.shape)} != x {tuple(x.shape)}")
     check(_lib.load().cfd_cast_copy(xp, ldx, _DT[x.dtype], yp, ldy, _DT[out.dtype], pixels, x.shape[-1], _stream()),
           "cfd_cast_copy")
     return out
@@ -367,6 +423,9 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kind: int, cout: int, dw: torc
     yp, ldy = _nhwc(dy)
     if x.dtype != dy.dtype:
         raise _lib.CfdError("wgrad: x and dy must share the compute dtype")
+    want = (B, cout) if kind == DENSE else conv_out_shape(kind, B, Hi, Wi, cout)
+    _need(tuple(dy.shape) == tuple(want), f"wgrad dy is {tuple(dy.shape)}, kind {kind} on {tuple(x.shape)} gives {want}")
+    _numel(dw, cout * _TAPS[kind] * cin, "wgrad dw", torch.float32)
     d = ConvDesc(kind=kind, dtype=_DT[x.dtype], out_dtype=_DT[x.dtype], B=B, Hi=Hi, Wi=Wi, Cin=cin, Cout=cout,
                  ldx=ldx, ldy=ldy, act=0, leaky_slope=0.0, split_k=1)
     s = int(split_m) if split_m else lib.cfd_conv_wgrad_suggest_split(C.byref(d))
@@ -391,6 +450,8 @@ def transpose_weight(w: torch.Tensor, flip: bool, out: Optional[torch.Tensor] = 
     taps = w.numel() // (cout * cin)
     if out is None:
         out = torch.empty((cin,) + tuple(w.shape[1:-1]) + (cout,), dtype=w.dtype, device=w.device)
+    _numel(w, cout * taps * cin, "transpose_weight in")
+    _numel(out, cout * taps * cin, "transpose_weight out", w.dtype)
     check(_lib.load().cfd_transpose_weight(_ptr(w), _ptr(out), cout, taps, cin, int(flip), _DT[w.dtype], _stream()),
           "cfd_transpose_weight")
     return out
@@ -399,6 +460,7 @@ def transpose_weight(w: torch.Tensor, flip: bool, out: Optional[torch.Tensor] = 
 def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     xp, ldx = _nhwc(x)
     Cc = x.shape[-1]
+    _numel(out, Cc, "colsum out", torch.float32)
     check(_lib.load().cfd_colsum(xp, ldx, _ptr(out), x.numel() // Cc, Cc, _DT[x.dtype], _stream()), "cfd_colsum")
     return out
 
@@ -413,6 +475,16 @@ def bn_act_bwd(x, mean, var, gamma, beta, g1, act1, dx, dgamma, dbeta, g2=None, 
     dxp, lddx = (None, 0) if dx is None else _nhwc(dx)
     if drop_mask is not None and drop_rate == 0.0:
         drop_rate = 0.5
+    shp = tuple(x.shape)
+    _need(tuple(g1.shape) == shp and (g2 is None or tuple(g2.shape) == shp) and (dx is None or tuple(dx.shape) == shp),
+          f"bn_act_bwd: g1/g2/dx must have x's shape {shp}")
+    _need(g2 is None or g2.dtype == g1.dtype, "bn_act_bwd: g1 and g2 must share a dtype")
+    _need(dx is None or dx.dtype == g1.dtype, "bn_act_bwd: dx must have g1's dtype")
+    _need(drop_mask is None or (tuple(drop_mask.shape) == shp and drop_mask.dtype == torch.uint8 and drop_mask.is_contiguous()),
+          "bn_act_bwd: drop_mask must be dense uint8 of x's shape")
+    for t, n, what in ((mean, B * Cc, "mean"), (var, B * Cc, "var"), (gamma, Cc, "gamma"), (beta, Cc, "beta"),
+                       (dgamma, Cc, "dgamma"), (dbeta, Cc, "dbeta")):
+        _numel(t, n, "bn_act_bwd " + what, torch.float32)
     if sums is not None and (sums.numel() < 2 * B * Cc or sums.dtype != torch.float32 or not sums.is_contiguous()):
         raise _lib.CfdError("sums must be contiguous fp32 with at least 2*B*C elements")
     check(_lib.load().cfd_bn_act_bwd_ws(xp, ldx, _DT[x.dtype], _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), g1p, ldg1,
@@ -428,6 +500,10 @@ def act_bwd(y, g1, act1, dx, g2=None, act2=ACT_RELU, slope=LEAKY_SLOPE):
     g2p, ldg2 = (None, 0) if g2 is None else _nhwc(g2)
     dxp, lddx = _nhwc(dx)
     Cc = y.shape[-1]
+    shp = tuple(y.shape)
+    _need(tuple(g1.shape) == shp and tuple(dx.shape) == shp and (g2 is None or tuple(g2.shape) == shp),
+          f"act_bwd: g1/g2/dx must have y's shape {shp}")
+    _need(g1.dtype == y.dtype and dx.dtype == y.dtype and (g2 is None or g2.dtype == y.dtype), "act_bwd: one dtype")
     check(_lib.load().cfd_act_bwd(yp, ldy, g1p, ldg1, g2p, ldg2, dxp, lddx, y.numel() // Cc, Cc, act1, act2, slope,
                                   _DT[y.dtype], _stream()), "cfd_act_bwd")
     return dx
@@ -435,18 +511,28 @@ def act_bwd(y, g1, act1, dx, g2=None, act2=ACT_RELU, slope=LEAKY_SLOPE):
 
 def maxpool2_act_bwd(x, dy, dx, act, slope=LEAKY_SLOPE):
     B, H, W, Cc = x.shape
+    _need(H % 2 == 0 and W % 2 == 0 and tuple(dy.shape) == (B, H // 2, W // 2, Cc) and tuple(dx.shape) == (B, H, W, Cc)
+          and x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous() and dy.dtype == x.dtype
+          and dx.dtype == x.dtype, "maxpool2_act_bwd: dy must be (B,H/2,W/2,C), dx (B,H,W,C), dense, x's dtype")
     check(_lib.load().cfd_maxpool2_act_bwd(_ptr(x), _ptr(dy), _ptr(dx), B, H, W, Cc, act, slope, _DT[x.dtype],
                                            _stream()), "cfd_maxpool2_act_bwd")
     return dx
 
 
 def dropout_apply(x, out, rate=0.5, mask=None, seed=0, elem0=0):
+    _need(x.is_contiguous() and out.is_contiguous() and out.numel() == x.numel() and out.dtype == x.dtype,
+          "dropout_apply: out must match x")
+    _numel(mask, x.numel(), "dropout mask", torch.uint8)
     check(_lib.load().cfd_dropout_apply(_ptr(x), _ptr(out), _ptr(mask), x.numel(), rate, seed, elem0, _DT[x.dtype],
                                         _stream()), "cfd_dropout_apply")
     return out
 
 
 def bce_logits(z, loss, dz=None, target=None, target_const=1.0, grad_scale=1.0):
+    _need(z.is_contiguous() and z.dtype == torch.float32, "bce_logits: z must be dense fp32")
+    _numel(target, z.numel(), "bce target", torch.float32)
+    _numel(dz, z.numel(), "bce dz", torch.float32)
+    _numel(loss, 1, "bce loss", torch.float32)
     check(_lib.load().cfd_bce_logits(_ptr(z), _ptr(target), float(target_const), z.numel(), _ptr(loss), _ptr(dz),
                                      float(grad_scale), _stream()), "cfd_bce_logits")
 
@@ -455,12 +541,21 @@ MAE, MSE, HUBER = 0, 1, 2
 
 
 def field_loss(y, target, kind, loss, dout=None, weight=1.0, delta=1.0, dy_extra=None, sigmoid_grad=False):
+    _need(y.is_contiguous() and y.dtype == torch.float32, "field_loss: y must be dense fp32")
+    _need(target.numel() == y.numel(), f"field_loss: target {tuple(target.shape)} != prediction {tuple(y.shape)}")
+    _numel(target, y.numel(), "field_loss target", torch.float32)
+    _numel(dout, y.numel(), "field_loss dout", torch.float32)
+    _numel(dy_extra, y.numel(), "field_loss dy_extra", torch.float32)
+    _numel(loss, 1, "field_loss loss", torch.float32)
     check(_lib.load().cfd_field_loss(_ptr(y), _ptr(target), y.numel(), kind, float(delta), float(weight), _ptr(loss),
                                      _ptr(dy_extra), _ptr(dout), int(sigmoid_grad), _stream()), "cfd_field_loss")
 
 
 def adam_step(w, g, m, v, w_compute, alpha, beta1, beta2=0.999, eps=1e-7, grad_scale=1.0):
     n = w.numel()
+    for t, what in ((w, "w"), (g, "g"), (m, "m"), (v, "v")):
+        _numel(t, n, "adam " + what, torch.float32)
+    _numel(w_compute, n, "adam compute copy")
     cdt = BF16 if (w_compute is not None and w_compute.dtype == torch.bfloat16) else F32
     wc = w_compute if cdt == BF16 else None
     check(_lib.load().cfd_adam_step(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(wc), cdt, n, float(alpha), float(beta1),
@@ -469,17 +564,24 @@ def adam_step(w, g, m, v, w_compute, alpha, beta1, beta2=0.999, eps=1e-7, grad_s
 
 def bn_update_moving(mm, mv, mean, var, momentum=0.99):
     B, Cc = mean.shape
+    for t, nn in ((mm, Cc), (mv, Cc), (mean, B * Cc), (var, B * Cc)):
+        _numel(t, nn, "bn_update_moving operand", torch.float32)
     check(_lib.load().cfd_bn_update_moving(_ptr(mm), _ptr(mv), _ptr(mean), _ptr(var), B, Cc, momentum, _stream()),
           "cfd_bn_update_moving")
 
 
 def tap_scatter_grad(dz, dtaps, B, Hi, Wi, geom):
+    # geom 0: dz is the (B,2Hi,2Wi) image gradient of a stride-2 transposed conv; geom 1: (B,Hi,Wi) of a stride-1 conv
+    _numel(dz, B * Hi * Wi * (4 if geom == 0 else 1), "tap_scatter_grad dz", torch.float32)
+    _numel(dtaps, B * Hi * Wi * 16, "tap_scatter_grad dtaps", torch.float32)
     check(_lib.load().cfd_tap_scatter_grad(_ptr(dz), _ptr(dtaps), B, Hi, Wi, geom, _stream()), "cfd_tap_scatter_grad")
 
 
 def tap_dx(d, w, dx, ntaps):
     dxp, lddx = _nhwc(dx)
     Cc = dx.shape[-1]
+    _numel(d, (dx.numel() // Cc) * ntaps, "tap_dx d", torch.float32)
+    _numel(w, ntaps * Cc, "tap_dx w", dx.dtype)
     check(_lib.load().cfd_tap_dx(_ptr(d), _ptr(w), dxp, lddx, dx.numel() // Cc, Cc, ntaps, _DT[dx.dtype], _stream()),
           "cfd_tap_dx")
     return dx
@@ -488,6 +590,8 @@ def tap_dx(d, w, dx, ntaps):
 def tap_dw(d, x, dw, ntaps):
     xp, ldx = _nhwc(x)
     Cc = x.shape[-1]
+    _numel(d, (x.numel() // Cc) * ntaps, "tap_dw d", torch.float32)
+    _numel(dw, ntaps * Cc, "tap_dw dw", torch.float32)
     check(_lib.load().cfd_tap_dw(_ptr(d), xp, ldx, _ptr(dw), x.numel() // Cc, Cc, ntaps, _DT[x.dtype], _stream()),
           "cfd_tap_dw")
     return dw
@@ -497,6 +601,14 @@ def conv_first_wgrad(x, x2, dpre, dw, db, ksize, stride):
     B, Hi, Wi, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[-1]
     dp, ldd = _nhwc(dpre)
+    cout = dpre.shape[-1]
+    _need(x.is_contiguous() and x.dtype == torch.float32 and
+          (x2 is None or (tuple(x2.shape[:3]) == (B, Hi, Wi) and x2.is_contiguous() and x2.dtype == torch.float32)),
+          "conv_first_wgrad: x / x2 must be dense fp32 images of one shape")
+    _need(tuple(dpre.shape) == (B, Hi // stride, Wi // stride, cout),
+          f"conv_first_wgrad: dpre {tuple(dpre.shape)} does not match x {tuple(x.shape)} at stride {stride}")
+    _numel(dw, cout * ksize * ksize * (c1 + c2), "conv_first_wgrad dw", torch.float32)
+    _numel(db, cout, "conv_first_wgrad db", torch.float32)
     check(_lib.load().cfd_conv_first_wgrad(_ptr(x), _ptr(x2), c1, c2, dp, ldd, _ptr(dw), _ptr(db), B, Hi, Wi,
                                            dpre.shape[-1], ksize, stride, _DT[dpre.dtype], _stream()),
           "cfd_conv_first_wgrad")

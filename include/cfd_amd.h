@@ -143,6 +143,11 @@ int cfd_bn_apply(const void *x, int ldx, int x_dtype, const float *stat_sum, con
                  const float *beta, float *mean, float *var, const uint8_t *drop_mask, float drop_rate,
                  uint64_t drop_seed, int64_t sample0, void *y, int ldy, void *y2, int ldy2, int B, int HW, int C,
                  float eps, int act, int act2, float leaky_slope, int dtype, void *stream);
+/* Device-resident dropout epoch (no counterpart in the reference): forward kernels in RNG mode whose drop_seed has
+ * bit 63 set use seed + epoch * odd_constant.  set != 0: epoch = value; else epoch += value.  Lets a captured HIP
+ * graph (whose kernel arguments are frozen) draw fresh dropout per replay.  Seeds below 2^63 ignore the epoch, so a
+ * training step's backward always reproduces its forward mask; cfd_bn_act_bwd refuses bit-63 seeds. */
+int cfd_dropout_epoch(uint64_t value, int set, void *stream);
 /* the keep-mask (0/1 bytes, [B][HW][C]) that cfd_bn_act's RNG mode applies for the same arguments */
 int cfd_dropout_mask(uint8_t *mask, int64_t sample0, int B, int HW, int C, float rate, uint64_t seed, void *stream);
 

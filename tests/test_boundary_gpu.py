@@ -83,3 +83,41 @@ def test_keras_surface_shapes():
     out = gan.train_on_batch([x], [np.ones((2, 4, 32, 1)), np.clip(y, 0, 1)])
     assert len(out) == 3 and abs(out[0] - (out[1] + 100 * out[2])) < 1e-3 * max(1, abs(out[0]))
     assert g.count_params() == 103_314_177 and d.count_params() == 27_821_953
+
+
+def test_predict_hip_graph_and_empty_batch(monkeypatch):
+    """CFD_AMD_GRAPHS=1: small-batch predict replays one captured HIP graph.  The DeltaP CNN (no dropout at inference)
+    must give the eager result bit for bit; the generators draw fresh dropout on every replay (device-resident epoch,
+    cfd_dropout_epoch) and stay within the spread of eager draws.  An empty batch returns an empty array."""
+    from cfd_amd import keras_api as K, synthetic
+    x, _, _ = synthetic.model_batch([0, 1])
+    c = K.define_cnn_model((64, 512, 1))
+    g = K.define_generator_P((64, 512, 1))
+    monkeypatch.setenv("CFD_AMD_GRAPHS", "0")
+    yc = c.predict(x)
+    ye = np.stack([g.predict(x) for _ in range(4)])
+    monkeypatch.setenv("CFD_AMD_GRAPHS", "1")
+    for _ in range(2):
+        assert np.array_equal(c.predict(x), yc)
+    a, b = g.predict(x), g.predict(x)
+    assert a.shape == (2, 64, 512, 1) and np.isfinite(a).all() and (a != b).any()
+    spread = np.abs(ye - ye.mean(0)).max()
+    assert np.abs(a - ye.mean(0)).max() < 4 * spread + 1e-3 and np.abs(b - ye.mean(0)).max() < 4 * spread + 1e-3
+    assert g.predict(x[:0]).shape == (0, 64, 512, 1) and c.predict(x[:0]).shape == (0, 1)
+    # the epoch the replays advanced touches only bit-63 seeds: training-range seeds still give one mask in the
+    # forward (elementwise.hip) and backward (train.hip) kernels, and the backward refuses an epoch-keyed seed
+    import torch
+    from cfd_amd import _lib, ops
+    t = torch.randn((4, 256), device="cuda")
+    y = torch.empty_like(t)
+    ops.dropout_apply(t, y, 0.5, seed=9, elem0=0)
+    assert torch.equal(y, t * ops.dropout_mask((4, 1, 1, 256), 0.5, 9).view(4, 256).float() * 2.0)
+    m1 = ops.dropout_mask((1, 2, 2, 64), 0.5, (1 << 63) | 5)
+    ops.dropout_epoch(1)
+    assert not torch.equal(m1, ops.dropout_mask((1, 2, 2, 64), 0.5, (1 << 63) | 5))
+    r = torch.zeros((1, 2, 2, 64), device="cuda")
+    v = torch.ones((1, 64), device="cuda")
+    with pytest.raises(_lib.CfdError):
+        ops.bn_act_bwd(r, v, v, v[0], v[0], r, ops.ACT_RELU, torch.empty_like(r), torch.zeros(64, device="cuda"),
+                       torch.zeros(64, device="cuda"), drop_rate=0.5, drop_seed=(1 << 63) | 5)
+    ops.dropout_epoch(0, set_=True)

@@ -121,3 +121,34 @@ def test_keras_layout_round_trip():
     assert set(back) == set(po)
     for k in po:
         assert np.array_equal(back[k], po[k]), k
+
+
+def test_shape_mismatches_are_refused_on_the_host():
+    """The kernels never bounds-check: a net fed a grid it was not built for, or an op handed an output of the wrong
+    extent, must raise on the host before anything is launched."""
+    from cfd_amd import _lib, nets, ops
+    g = nets.Generator("P", dtype=torch.bfloat16)                  # built for 64x512
+    d = nets.Discriminator(dtype=torch.bfloat16)
+    big = torch.zeros((1, 128, 1024, 1), device="cuda")
+    small = torch.zeros((1, 64, 512, 1), device="cuda")
+    with pytest.raises(ValueError):
+        g.forward(big)
+    with pytest.raises(ValueError):
+        d.forward(big, small, training=True)
+    with pytest.raises(ValueError):
+        nets.CnnRegressor(dtype=torch.bfloat16).forward(big)
+    w = torch.zeros((64, 4, 4, 2), device="cuda")
+    with pytest.raises(_lib.CfdError):
+        ops.conv_first(big, small, w, None, 64, 4, 2, ops.ACT_LEAKY, torch.bfloat16)
+    with pytest.raises(_lib.CfdError):
+        ops.conv_first(small, small, w, None, 64, 4, 2, ops.ACT_LEAKY, torch.bfloat16,
+                       out=torch.empty((1, 16, 128, 64), dtype=torch.bfloat16, device="cuda"))
+    x = torch.zeros((1, 8, 64, 128), dtype=torch.bfloat16, device="cuda")
+    wk = torch.zeros((128, 4, 4, 128), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(_lib.CfdError):
+        ops.conv_forward(x, wk, None, ops.CONV_K4S2, 128, out=torch.empty((1, 8, 64, 128), dtype=torch.bfloat16, device="cuda"))
+    with pytest.raises(_lib.CfdError):
+        ops.conv_forward(x, wk[:64], None, ops.CONV_K4S2, 128)
+    with pytest.raises(_lib.CfdError):
+        ops.field_loss(small, big, ops.MAE, torch.zeros(1, device="cuda"))
+    torch.cuda.synchronize()

@@ -173,3 +173,41 @@ def test_cnn_train_on_batch(dtype, tol):
     v_ref = 100.0 * float(O.huber(y, O.cnn_forward(po, x)))
     v = tr.test_on_batch(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
     assert abs(v - v_ref) <= 5e-2 * max(1.0, abs(v_ref))
+
+
+def test_upscaled_4x_preprocess_and_train_step():
+    """BASELINE.json configs[4]: the 4x-pixel grid (128x1024) end to end -- scattered table -> GPU resample (bit-exact
+    vs the oracle) -> GPU sign mask / DeltaP / signed distance (bit-exact) -> one U GAN training step in fp32 against
+    the oracle's autograd step on the same 128x1024 input."""
+    from cfd_amd import nets, ops, synthetic, trainer
+    from oracle import dataset as OD, resample as OR
+    H, W = 128, 1024
+    arr = synthetic.scattered_case(5, jitter=0.1)
+    rows = ops.resample_nearest([arr], H, W)[0]
+    ref_rows, ties = OR.resample(arr, H, W, return_ties=True)
+    assert not ties.any() and np.array_equal(rows, ref_rows)
+    sdf, dp = ops.dataset_grids(rows[:, 4].reshape(1, H, W), cell=4.0 / H)
+    sdf_ref, _p, u_ref, dp_ref = OD.grids_from_table(rows[:, 4], rows[:, 3], H, W)
+    assert np.array_equal(sdf[0], sdf_ref) and dp[0] == dp_ref
+    x = sdf[0][None, :, :, None].astype(np.float32)
+    u = (u_ref / u_ref.max())[None, :, :, None].astype(np.float32)
+
+    shape = (H, W, 1)
+    pg = O.init_generator("U", seed=31, jitter=True)
+    pd = O.init_discriminator(seed=32, jitter=True)
+    g = nets.Generator("U", image_shape=shape, dtype=torch.float32)
+    d = nets.Discriminator(image_shape=shape, dtype=torch.float32)
+    g.params.load_keras(O.to_numpy(pg))
+    d.params.load_keras(O.to_numpy(pd))
+    tr = trainer.GanTrainer(g, d)
+    gen = torch.Generator().manual_seed(4)
+    masks = [(torch.rand(s, generator=gen) < 0.5) for s in O.generator_dropout_shapes("U", 1, shape)]
+    lab = np.ones((1, H // 16, W // 16, 1), dtype=np.float32)
+    ref, gref = O.gan_train_on_batch(pg, pd, O.KerasAdam(4e-4, 0.5), "U", x, lab, u, [m.float() for m in masks],
+                                     return_grads=True)
+    out = tr.train_on_batch(torch.from_numpy(x).cuda(), 1.0, torch.from_numpy(u).cuda(),
+                            masks=[m.to(torch.uint8).cuda() for m in masks])
+    for a, b in zip(out, ref):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (out, ref)
+    wg = compare_grads(grads_keras(g), gref, "g.", 1e-2)
+    print(f"4x grid U fp32: losses {out} vs {ref}; worst grad rel-L2 {wg:.3e}")
