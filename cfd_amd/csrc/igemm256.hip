@@ -40,6 +40,7 @@ struct Igemm256Params {
   unsigned xbytes, wbytes;   // buffer sizes for the range check
   int tapinfo[4][16];        // per class, per tap: (dy*Wi + dx) pixel offset << 8 | weight tap index
   short tapdy[4][16], tapdx[4][16];
+  int cls_fast;              // block order: 1 = the sub-pixel classes of one pixel tile are adjacent blocks
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -89,9 +90,10 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int nt = bid % p.ntiles; bid /= p.ntiles;
-  const int mt = bid % p.mtiles; bid /= p.mtiles;
-  const int cls = bid % p.nclass;
-  const int sk = bid / p.nclass;
+  int mt, cls;
+  if (P.cls_fast) { cls = bid % p.nclass; bid /= p.nclass; mt = bid % p.mtiles; bid /= p.mtiles; }
+  else { mt = bid % p.mtiles; bid /= p.mtiles; cls = bid % p.nclass; bid /= p.nclass; }
+  const int sk = bid;
   const int ph = cls >> 1, pw = cls & 1;
   const int m0 = mt * 256, n0 = nt * 256;
   const int S = (p.kind == CFD_CONV_K4S2) ? 2 : 1;
@@ -434,9 +436,10 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int nt = bid % p.ntiles; bid /= p.ntiles;
-  const int mt = bid % p.mtiles; bid /= p.mtiles;
-  const int cls = bid % p.nclass;
-  const int sk = bid / p.nclass;
+  int mt, cls;
+  if (P.cls_fast) { cls = bid % p.nclass; bid /= p.nclass; mt = bid % p.mtiles; bid /= p.mtiles; }
+  else { mt = bid % p.mtiles; bid /= p.mtiles; cls = bid % p.nclass; bid /= p.nclass; }
+  const int sk = bid;
   const int ph = cls >> 1, pw = cls & 1;
   const int m0 = mt * 256, n0 = nt * 128;
   const int S = (p.kind == CFD_CONV_K4S2) ? 2 : 1;
@@ -659,6 +662,11 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   p.nblocks = p.mtiles * p.ntiles * p.nclass * p.split_k;
   P.xbytes = (unsigned)x_bytes(p, es);
   P.wbytes = (unsigned)w_bytes(p, es);
+  // block order of the sub-pixel classes: interleaved (the four classes of a pixel tile run side by side on one XCD
+  // and share the input rows in its L2) when the activations outweigh the weights, else class-major (each class
+  // streams only its own quarter of the weights)
+  const int co = tuning(CFD_TUNE_CLASS_ORDER);
+  P.cls_fast = p.nclass > 1 && (co < 0 ? x_bytes(p, es) > w_bytes(p, es) : co == 1);
   for (int cls = 0; cls < p.nclass; ++cls)
     for (int t = 0; t < p.ntaps; ++t) {
       int dy, dx, wt;

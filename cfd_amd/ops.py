@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, CONV_K3S1, CONV_K4S1, CONV_K4S2, CONVT_K4S2,
-                   DENSE, F32, TUNE_IGEMM256, TUNE_IGEMM256_PD, TUNE_WGRAD256, ConvDesc, check)
+                   DENSE, F32, TUNE_CLASS_ORDER, TUNE_IGEMM256, TUNE_IGEMM256_PD, TUNE_WGRAD256, ConvDesc, check)
 
 LEAKY_SLOPE = 0.2
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
@@ -87,11 +87,22 @@ class KernelTimer:
     stream IS the stream the kernels are launched on) and records their algorithmic FLOPs.
     Used by bench.py for the `roofline` object; off by default (zero overhead)."""
 
-    def __init__(self):
+    def __init__(self, max_launches: int = 1024):
         self.records = []   # (tag, flops, start_event, end_event)
+        # torch creates the HIP event at its first record(): do that here, outside every bracket, so that a bracket
+        # costs two hipEventRecord calls and nothing else
+        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * max_launches)]
+        for e in self.pool:
+            e.record()
+
+    def pair(self):
+        if len(self.pool) >= 2:
+            return self.pool.pop(), self.pool.pop()
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
         global _timer
+        torch.cuda.synchronize()
         _timer = self
         return self
 
@@ -158,7 +169,7 @@ def conv_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
             check(-1, "cfd_conv_workspace_bytes")
         ws = _workspace(nbytes, x.device)
     if _timer is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = _timer.pair()
         e0.record()
     if fused:
         check(lib.cfd_conv_forward_stats(C.byref(d), xp, _ptr(w), _ptr(bias), yp, _ptr(ws), _ptr(stats[0]),
@@ -434,7 +445,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kind: int, cout: int, dw: torc
     if s > 1 and ws is None:
         dw.zero_()  # memset node on the stream; the kernel accumulates with atomics
     if _timer is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = _timer.pair()
         e0.record()
     check(lib.cfd_conv_wgrad_ws(C.byref(d), xp, yp, _ptr(dw), s, _ptr(ws), _stream()), "cfd_conv_wgrad_ws")
     if _timer is not None:

@@ -39,8 +39,11 @@ const char *cfd_last_error(void);
  *   CFD_TUNE_IGEMM256     -1 heuristic (default) | 0 never | 1 whenever eligible: use the 256x256 ping-pong
  *                         bf16 implicit-GEMM kernel instead of the 128x128 one
  *   CFD_TUNE_IGEMM256_PD  schedule variant of that kernel (see igemm256.hip; default = two phases per K tile)
- *   CFD_TUNE_WGRAD256     -1 heuristic | 0 never | 1 whenever eligible: the 256x256 ping-pong weight-gradient kernel */
-typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_WGRAD256 = 2, CFD_TUNE_COUNT = 3 } cfd_tuning_key;
+ *   CFD_TUNE_WGRAD256     -1 heuristic | 0 never | 1 whenever eligible: the 256x256 ping-pong weight-gradient kernel
+ *   CFD_TUNE_CLASS_ORDER  -1 heuristic | 0 class-major | 1 class-interleaved block order of the sub-pixel classes of a
+ *                         transposed convolution (interleaved: the four classes of one pixel tile share L2 lines) */
+typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_WGRAD256 = 2, CFD_TUNE_CLASS_ORDER = 3,
+               CFD_TUNE_COUNT = 4 } cfd_tuning_key;
 int cfd_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------

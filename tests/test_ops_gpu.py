@@ -118,8 +118,10 @@ def test_conv_forward_igemm256(kind, B, H, W, cin, cout, split_k, dtype, pd):
             wp = ops.pack_conv_weight(wk.to(dev), dtype)
             xin, oshape = x, tuple(ref.shape)
         # fp32 output, no activation: only the accumulation order differs from the oracle
+        ops.set_tuning(ops.TUNE_CLASS_ORDER, 1)      # sub-pixel classes interleaved; the second call runs class-major
         y = ops.conv_forward(xin.to(dev).to(dtype), wp, bias.to(dev), code, cout, out_dtype=torch.float32,
                              split_k=split_k)
+        ops.set_tuning(ops.TUNE_CLASS_ORDER, 0)
         # bf16 output + LeakyReLU into a channel slice
         buf = torch.zeros(oshape[:-1] + (cout + 64,), dtype=dtype, device=dev)
         ops.conv_forward(xin.to(dev).to(dtype), wp, bias.to(dev), code, cout, act=ops.ACT_LEAKY, out=buf[..., 64:],
@@ -128,6 +130,7 @@ def test_conv_forward_igemm256(kind, B, H, W, cin, cout, split_k, dtype, pd):
     finally:
         ops.set_tuning(ops.TUNE_IGEMM256, -1)
         ops.set_tuning(ops.TUNE_IGEMM256_PD, -1)
+        ops.set_tuning(ops.TUNE_CLASS_ORDER, -1)
     assert relerr(y.cpu(), ref) <= 1e-4
     assert relerr(buf[..., 64:].float().cpu(), O.leaky(ref)) <= TOL[dtype]
     assert float(buf[..., :64].float().abs().max()) == 0.0
