@@ -361,7 +361,10 @@ static bool use_igemm256(const IgemmParams &p, int dtype) {
   const int blocks = cdiv(p.M, 256) * (p.Cout / igemm256_ntile(p)) * p.nclass;
   const int s = split_k_256(p);
   // (an f32 K tile is 8x the MFMA time of a bf16 one, so a much shorter slice already amortises the prologue)
-  return blocks * s >= 128 && (p.ntaps * p.cpt) / s >= (dtype == CFD_BF16 ? 32 : 8);
+  // (B = 128: with >= 4 tiles queued per CU a 16-K-tile bf16 layer -- DeltaP g4, K = 9 x 128 -- runs 0.97 PFLOP/s
+  //  here against 0.70 on the 128x128 kernel)
+  const int kt = (p.ntaps * p.cpt) / s;
+  return blocks * s >= 128 && (kt >= (dtype == CFD_BF16 ? 32 : 8) || (blocks >= 1024 && kt >= 16));
 }
 
 extern "C" int cfd_conv_suggest_split_k(const cfd_conv_desc *d) {
