@@ -76,6 +76,7 @@ SIGNATURES = {
     "cfd_conv_first_wgrad": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cfd_dataset_workspace_bytes": (_i64, [_i, _i, _i]),
     "cfd_dataset_grids": (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
+    "cfd_eval_metrics": (_i, [_vp, _f, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "cfd_resample_workspace_bytes": (_i64, [_i, _i, _i]),
     "cfd_resample_nearest": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _d, _d, _d, _vp, _vp, _vp]),
 }

@@ -191,15 +191,6 @@ def train(field: str, argv=None, image_shape=(64, 512, 1), models=None):
     return hist
 
 
-def _row_cosine(y, Y):
-    cs = []
-    for a, b in zip(y, Y):
-        if not np.all(b == 0):
-            na, nb = np.linalg.norm(a), np.linalg.norm(b)
-            cs.append(float(a @ b / (na * nb)) if na > 0 and nb > 0 else 0.0)
-    return float(np.mean(cs)) if cs else float("nan")
-
-
 def evaluate(field: str, processed_folder: str, model_path: Optional[str] = None, out_dir: Optional[str] = None,
              model=None, batch: int = 32, image_shape=(64, 512, 1), holdout_last_fraction: float = 0.1):
     """valid.py / test.py: per-case prediction on the held-out tail of the folder (U/valid.py:44-51 takes the
@@ -226,9 +217,20 @@ def evaluate(field: str, processed_folder: str, model_path: Optional[str] = None
         p_max = float(np.asarray(dps[:train_size]).max())
         y_test, scale = np.asarray(dps[-test_size:], dtype="float32"), p_max
     os.makedirs(out_dir, exist_ok=True)
-    preds = [model.predict(x_test[s:s + batch]) for s in range(0, test_size, batch)]
-    pred = np.concatenate(preds, axis=0) * scale
     rows, mean_err = [], 0.0
+    if field == "DeltaP":
+        pred = np.concatenate([model.predict(x_test[s:s + batch]) for s in range(0, test_size, batch)], axis=0) * scale
+    else:
+        # fields stay on the device: one metrics launch per batch, four numbers per case come back (U/valid.py:86-111)
+        import torch
+        from . import ops
+        metrics = []
+        for s in range(0, test_size, batch):
+            y_dev = model.predict_on_device(x_test[s:s + batch])
+            t_dev = torch.from_numpy(np.ascontiguousarray(y_test[s:s + batch], dtype=np.float32)).to(y_dev.device)
+            m, _colmax = ops.eval_metrics(y_dev, t_dev, scale)
+            metrics.append(m)
+        metrics = np.concatenate(metrics, axis=0)
     csv_path = os.path.join(out_dir, f"error_test_{f['label']}.csv")
     with open(csv_path, "w", newline="") as fh:
         w = csv.writer(fh)
@@ -243,12 +245,7 @@ def evaluate(field: str, processed_folder: str, model_path: Optional[str] = None
                 row = [ix, Yv, yv, err, err / abs(Yv) * 100 if Yv else float("nan")]
                 mean_err += err
             else:
-                y, Y = pred[ix, :, :, 0], y_test[ix]
-                e = np.abs(Y - y)
-                mi = np.unravel_index(np.argmax(e), e.shape)
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    pct = float(e[mi] / Y[mi] * 100)
-                row = [ix, float(e.max()), pct, float(e.sum() / e.size), _row_cosine(y, Y)]
+                row = [ix] + [float(v) for v in metrics[ix]]
                 mean_err += row[3]
             w.writerow([str(v) for v in row])
             rows.append(row)

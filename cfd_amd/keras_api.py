@@ -161,6 +161,11 @@ class GeneratorModel(Model):
             return g(xd).cpu().numpy()
         return self.net.forward(xd, seed=self._next_seed()).cpu().numpy()
 
+    def predict_on_device(self, x) -> torch.Tensor:
+        """predict without the copy back to the host (not in Keras): the evaluation drivers feed the result to
+        ops.eval_metrics and fetch a few numbers per case instead of the fields"""
+        return self.net.forward(_dev(x), seed=self._next_seed())
+
     __call__ = predict
 
 

@@ -413,6 +413,25 @@ def dataset_grids(p: np.ndarray, cell: float, device="cuda", return_device: bool
     return sdf.cpu().numpy(), dp.cpu().numpy()
 
 
+def eval_metrics(pred: torch.Tensor, target: torch.Tensor, scale: float = 1.0, want_colmax: bool = True):
+    """pred, target: fp32 device tensors (n, H, W) (a trailing channel axis of 1 is accepted).  Returns
+    (metrics (n, 4) float64 numpy: max |Y-y|, % error at the arg-max pixel, mean |Y-y|, mean row cosine similarity;
+     colmax (n, W) float32 numpy or None) -- U/valid.py:86-111 on the device, one launch for all cases."""
+    if pred.dim() == 4 and pred.shape[-1] == 1:
+        pred = pred[..., 0]
+    if target.dim() == 4 and target.shape[-1] == 1:
+        target = target[..., 0]
+    _need(pred.dim() == 3 and tuple(pred.shape) == tuple(target.shape), f"eval_metrics: pred {tuple(pred.shape)} vs target {tuple(target.shape)}")
+    _need(pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.is_contiguous() and target.is_contiguous(),
+          "eval_metrics: dense fp32 tensors")
+    n, H, W = pred.shape
+    out = torch.empty((n, 4), dtype=torch.float64, device=pred.device)
+    col = torch.empty((n, W), dtype=torch.float32, device=pred.device) if want_colmax else None
+    check(_lib.load().cfd_eval_metrics(_ptr(pred), float(scale), _ptr(target), n, H, W, _ptr(out), _ptr(col), _stream()),
+          "cfd_eval_metrics")
+    return out.cpu().numpy(), (col.cpu().numpy() if want_colmax else None)
+
+
 # ----------------------------------------------------------------------------------------
 # training-step kernels (backward, losses, optimiser)
 # ----------------------------------------------------------------------------------------

@@ -279,6 +279,18 @@ int64_t cfd_dataset_workspace_bytes(int ncase, int H, int W);
 int cfd_dataset_grids(const double *p, int ncase, int H, int W, double cell, double *sdf, double *delta_p, int *flags,
                       void *workspace, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Evaluation metrics of the valid / test drivers (U/valid.py:86-111): per case, from the prediction y = pred * scale and
+ * the CFD field Y (both fp32 [ncase][H][W], device):
+ *   out[c][0] = max |Y - y|                        (:100-101)
+ *   out[c][1] = |Y - y| / Y * 100 at the arg-max pixel, first occurrence in row-major order, fp32 arithmetic (:103-105)
+ *   out[c][2] = sum |Y - y| / (H * W)              (:96-97)
+ *   out[c][3] = mean over rows with Y[i] != 0 of the cosine similarity of y[i] and Y[i]; NaN if there is none (:107-111)
+ *   colmax    fp32 [ncase][W] (may be NULL) = max over rows of |Y - y| per column (:100, the error surface of :119-139)
+ * ---------------------------------------------------------------------------------- */
+int cfd_eval_metrics(const float *pred, float scale, const float *target, int ncase, int H, int W, double *out,
+                     float *colmax, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

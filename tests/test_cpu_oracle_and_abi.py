@@ -109,3 +109,21 @@ def test_oracle_signed_distance_analytic():
     assert ((d < 0) == (phi < 0)).all()
     with pytest.raises(ValueError):
         OD.signed_distance(np.ones((8, 8)), dx)
+
+
+def test_oracle_metrics_pinned_to_sklearn():
+    """U/valid.py:110 calls scikit-learn's cosine_similarity per row; the oracle's numpy restatement must equal it"""
+    from sklearn.metrics.pairwise import cosine_similarity
+    from oracle import metrics as M
+    rng = np.random.default_rng(0)
+    y = rng.random((8, 40), dtype=np.float32)
+    Y = rng.random((8, 40), dtype=np.float32)
+    Y[2] = 0
+    y[5] = 0
+    for i in range(8):
+        assert abs(M.row_cosine(y[i], Y[i]) - float(cosine_similarity([y[i]], [Y[i]])[0][0])) <= 1e-6
+    emax, pct, emean, cos, col = M.field_metrics(y, Y)
+    e = np.abs(Y - y)
+    assert emax == e.max() and col.shape == (40,) and abs(emean - e.mean()) < 1e-6
+    ref = np.mean([cosine_similarity([y[i]], [Y[i]])[0][0] for i in range(8) if i != 2])
+    assert abs(cos - ref) < 1e-6

@@ -347,3 +347,33 @@ def test_dataset_grids_bit_exact(H, W):
     # no zero contour: skfmm raises, so do we
     with pytest.raises(ValueError):
         ops.dataset_grids(np.ones((1, H, W)), cell=4.0 / H)
+
+
+@pytest.mark.parametrize("H,W", [(64, 512), (128, 1024), (5, 37)])
+def test_eval_metrics(H, W):
+    """U/valid.py:86-111 on the device against the numpy restatement: maximum error and the percentage at its arg-max
+    pixel exactly (fp32 element arithmetic), the two means within fp32 summation noise; zero target rows are skipped,
+    a zero prediction row counts as cosine 0, and a case whose target is all zero gives NaN."""
+    from cfd_amd import ops
+    from oracle import metrics as M
+    rng = np.random.default_rng(H)
+    n = 4
+    y = rng.random((n, H, W), dtype=np.float32)
+    Y = rng.random((n, H, W), dtype=np.float32)
+    Y[0, :2] = 0
+    y[1, 3] = 0
+    Y[2] = 0
+    Y[3, 1, 5] = y[3, 1, 5] * 0.5 + 7.0          # a clear maximum
+    Y[3, 4, 6] = y[3, 4, 6] * 0.5 + 7.0 + (Y[3, 1, 5] - y[3, 1, 5] * 0.5 - 7.0)
+    scale = 0.5
+    m, col = ops.eval_metrics(torch.from_numpy(y).cuda(), torch.from_numpy(Y).cuda()[..., None], scale)
+    for c in range(n):
+        emax, pct, emean, cos, colmax = M.field_metrics(y[c] * np.float32(scale), Y[c])
+        assert m[c, 0] == emax
+        assert m[c, 1] == pct or (np.isnan(pct) and np.isnan(m[c, 1])) or (np.isinf(pct) and m[c, 1] == pct)
+        assert abs(m[c, 2] - emean) <= 1e-5 * emean
+        assert (np.isnan(cos) and np.isnan(m[c, 3])) or abs(m[c, 3] - cos) <= 1e-5
+        assert np.array_equal(col[c], colmax)
+    assert np.isnan(m[2, 3])
+    e, _ = ops.eval_metrics(torch.zeros((0, H, W), device="cuda"), torch.zeros((0, H, W), device="cuda"))
+    assert e.shape == (0, 4)
