@@ -74,10 +74,15 @@ class TrainJob:
         self.gtr = trainer.GanTrainer(self.g, self.d)
 
     def step(self, x, y, step, sample0):
+        """The reference's four calls (U/train.py:119-125).  The generator's forwards do not read D's weights, so
+        they are enqueued between a D update's all-reduce launch and its Adam step: same arithmetic as the
+        reference's order, with D's gradient exchange hidden behind them when world > 1."""
+        self.dtr.begin(x, y, 1.0)                                         # d_model.train_on_batch([A,B], ones) ...
         fake = self.g.forward(x, seed=2 * step, sample0=sample0)          # generate_fake_samples (utils.py:52-62)
-        self.dtr.train_on_batch(x, y, 1.0)                                # d_model.train_on_batch([A,B], ones)
-        self.dtr.train_on_batch(x, fake, 0.0)                             # d_model.train_on_batch([A,fake], zeros)
-        return self.gtr.train_on_batch(x, 1.0, y, seed=2 * step + 1, sample0=sample0)   # gan_model.train_on_batch
+        self.dtr.finish()                                                 # ... its all-reduce, Adam
+        self.dtr.begin(x, fake, 0.0)                                      # d_model.train_on_batch([A,fake], zeros)
+        return self.gtr.train_on_batch(x, 1.0, y, seed=2 * step + 1, sample0=sample0,
+                                       before_d=self.dtr.finish)          # gan_model.train_on_batch
 
 
 def run_step(models, x, step, sample0):

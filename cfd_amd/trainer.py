@@ -124,8 +124,16 @@ class DiscriminatorTrainer:
         self.opt = Adam(d.params, lo, d.params.n_trainable, lr, beta_1)
         self.dp = _DP()
         self.loss = torch.zeros(1, dtype=torch.float32, device=d.device)
+        self._pending = None
 
     def train_on_batch(self, src: torch.Tensor, tgt: torch.Tensor, label: float) -> float:
+        self.begin(src, tgt, label)
+        return self.finish()
+
+    def begin(self, src: torch.Tensor, tgt: torch.Tensor, label: float) -> None:
+        """forward + backward + launch of the gradient all-reduce.  Work that does not read D's weights (the
+        generator's forward) may be enqueued between begin() and finish(): it then overlaps the collective, which
+        D's short backward cannot hide by itself."""
         d, P = self.d, self.d.params
         B = src.shape[0]
         P.grad.zero_()
@@ -135,11 +143,18 @@ class DiscriminatorTrainer:
         ops.bce_logits(logits, self.loss, dz, target_const=label)
         d.backward(dz, src, tgt, train_convs=self.train_convs)
         self.dp.reduce_async(P.grad[self.opt.lo:self.opt.hi])
+        self._pending = B
+
+    def finish(self) -> float:
+        """wait for the all-reduce, Adam, moving statistics; returns the loss (one host sync)"""
+        B, self._pending = self._pending, None
+        if B is None:
+            raise RuntimeError("finish() without begin()")
         self.dp.wait()
         self.opt.step(self.dp.grad_scale)
         if self.train_convs:
-            P.refresh_transposed()
-        d.update_moving(B)
+            self.d.params.refresh_transposed()
+        self.d.update_moving(B)
         return float(self.loss.item())
 
 
@@ -159,25 +174,29 @@ class GanTrainer:
         self.losses = torch.zeros(2, dtype=torch.float32, device=g.device)
         self.step_count = 0
 
-    def _forward_losses(self, src, label, tgt, masks, seed, sample0, training: bool, want_grads: bool):
+    def _forward_losses(self, src, label, tgt, masks, seed, sample0, training: bool, want_grads: bool, before_d=None):
         g, d = self.g, self.d
         B = src.shape[0]
         self.losses.zero_()
         fake = g.forward(src, masks=masks, seed=seed, sample0=sample0)
+        if before_d is not None:
+            before_d()
         logits = d.forward(src, fake, training=training, want_logits=True)
         dz_d = d.buf(d.plan(B), "dlogits", logits.shape, torch.float32) if want_grads else None
         ops.bce_logits(logits, self.losses[0:1], dz_d, target_const=label)
         return fake, dz_d
 
     def train_on_batch(self, src: torch.Tensor, label: float, tgt: torch.Tensor, masks=None, seed: Optional[int] = None,
-                       sample0: int = 0) -> List[float]:
+                       sample0: int = 0, before_d=None) -> List[float]:
+        """`before_d` (optional callable) runs after the generator's forward and before D is first read: a pending
+        DiscriminatorTrainer.finish goes there, so that D's all-reduce overlaps the generator's forward."""
         g, d = self.g, self.d
         B = src.shape[0]
         self.step_count += 1
         seed = self.step_count if seed is None else seed
         g.params.grad.zero_()
-        d.params.grad.zero_()
-        fake, dz_d = self._forward_losses(src, label, tgt, masks, seed, sample0, True, True)
+        fake, dz_d = self._forward_losses(src, label, tgt, masks, seed, sample0, True, True, before_d)
+        d.params.grad.zero_()      # after a pending D step (before_d) has consumed its gradients
         dfake = d.backward(dz_d, src, fake, train_convs=False, want_input_grad=True)
         # D's BN gradients are complete: overlap their all-reduce (and G's, bucket by bucket) with G's backward
         self.dp.reduce_async(d.params.grad[self.opt_dbn.lo:self.opt_dbn.hi])

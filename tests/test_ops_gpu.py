@@ -46,6 +46,8 @@ def q(t, dtype):
     ("convT", 1, 1, 8, 64, 256),       # d1: 1x8 input
     ("dense", 5, 1, 1, 4096, 256),     # fc (split-K)
     ("dense", 3, 1, 1, 128, 1),        # fc3
+    ("dense", 7, 1, 1, 64, 128),       # a single K tile
+    ("k4s2", 16, 4, 32, 256, 256),     # weight-streaming shape: 64 K tiles, split-K chosen by the library
 ])
 def test_conv_forward(kind, B, H, W, cin, cout, dtype):
     from cfd_amd import ops

@@ -211,3 +211,41 @@ def test_upscaled_4x_preprocess_and_train_step():
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (out, ref)
     wg = compare_grads(grads_keras(g), gref, "g.", 1e-2)
     print(f"4x grid U fp32: losses {out} vs {ref}; worst grad rel-L2 {wg:.3e}")
+
+
+def test_pipelined_step_equals_reference_order():
+    """bench.py's training step enqueues the generator's forwards between a D update's all-reduce launch and its
+    Adam step (DiscriminatorTrainer.begin / finish, GanTrainer before_d).  Same arithmetic as the reference's order
+    (U/train.py:119-125): two steps of each from identical weights must give the same losses and weights."""
+    from cfd_amd import nets, trainer
+    B = 2
+    x, u, _ = inputs(B)
+    x, u = torch.from_numpy(x).cuda(), torch.from_numpy(u).cuda()
+
+    def make():
+        g = nets.Generator("P", dtype=torch.float32, seed=5)
+        d = nets.Discriminator(dtype=torch.float32, seed=6)
+        return g, d, trainer.DiscriminatorTrainer(d), trainer.GanTrainer(g, d)
+
+    g1, d1, dtr1, gtr1 = make()
+    g2, d2, dtr2, gtr2 = make()
+    out1, out2 = [], []
+    for step in range(2):
+        fake = g1.forward(x, seed=2 * step)
+        a = dtr1.train_on_batch(x, u, 1.0)
+        b = dtr1.train_on_batch(x, fake, 0.0)
+        out1.append([a, b] + gtr1.train_on_batch(x, 1.0, u, seed=2 * step + 1))
+
+        dtr2.begin(x, u, 1.0)
+        fake = g2.forward(x, seed=2 * step)
+        a = dtr2.finish()
+        dtr2.begin(x, fake, 0.0)
+        res = {}
+        c = gtr2.train_on_batch(x, 1.0, u, seed=2 * step + 1, before_d=lambda: res.setdefault("b", dtr2.finish()))
+        out2.append([a, res["b"]] + c)
+    assert np.allclose(out1, out2, rtol=1e-5, atol=1e-6), (out1, out2)
+    for n1, n2 in ((g1, g2), (d1, d2)):
+        w1, w2 = n1.params.master, n2.params.master
+        assert float((w1 - w2).abs().max()) <= 1e-5 * float(w1.abs().max())
+    with pytest.raises(RuntimeError):
+        dtr2.finish()
