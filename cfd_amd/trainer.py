@@ -81,6 +81,13 @@ class _DP:
     def grad_scale(self) -> float:
         return 1.0 / self.world
 
+    def average_(self, t: torch.Tensor) -> None:
+        """t <- mean over ranks (small state that must stay identical on every rank, e.g. BatchNorm moving
+        statistics, whose per-rank updates see different samples)"""
+        if self.world > 1:
+            self.dist.all_reduce(t)
+            t.mul_(1.0 / self.world)
+
 
 class BackwardBuckets:
     """Overlap of the gradient all-reduce with the backward pass.  The main range [0, n_main) of the flat
@@ -155,6 +162,8 @@ class DiscriminatorTrainer:
         if self.train_convs:
             self.d.params.refresh_transposed()
         self.d.update_moving(B)
+        P = self.d.params
+        self.dp.average_(P.master[P.n_trainable:P.n_total])
         return float(self.loss.item())
 
 
@@ -211,6 +220,7 @@ class GanTrainer:
         self.opt_dbn.step(self.dp.grad_scale)
         g.params.refresh_transposed()
         d.update_moving(B)
+        self.dp.average_(d.params.master[d.params.n_trainable:d.params.n_total])
         l = self.losses.tolist()
         return [l[0] + self.field_weight * l[1], l[0], l[1]]
 
