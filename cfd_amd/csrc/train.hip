@@ -361,6 +361,38 @@ __global__ __launch_bounds__(256) void transpose_weight_kernel(const T *__restri
   }
 }
 
+// bf16, Cin % 8 == 0 && Cout % 8 == 0: 128(co) x 128(ci) tile, 16-B accesses on both sides (256-B runs per row)
+__global__ __launch_bounds__(256) void transpose_weight_bf16v_kernel(const bf16 *__restrict__ src, bf16 *__restrict__ dst,
+                                                                    int Cout, int taps, int Cin, int flip) {
+  __shared__ __attribute__((aligned(16))) unsigned short tile[128][136];
+  const int t = blockIdx.z;
+  const int co0 = blockIdx.y * 128, ci0 = blockIdx.x * 128;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = i * 256 + tid, r = idx >> 4, c8 = (idx & 15) * 8;
+    const int co = co0 + r, ci = ci0 + c8;
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (co < Cout && ci < Cin) v = *(const uint4 *)(src + ((size_t)co * taps + t) * Cin + ci);
+    *(uint4 *)&tile[r][c8] = v;
+  }
+  __syncthreads();
+  const int td = flip ? taps - 1 - t : t;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = i * 256 + tid, r = idx & 127, c8 = (idx >> 7) * 8;   // consecutive lanes: consecutive ci rows
+    const int ci = ci0 + r, co = co0 + c8;
+    if (ci < Cin && co < Cout) {
+      unsigned short e[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = tile[c8 + k][r];
+      uint4 v = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                 (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+      *(uint4 *)(dst + ((size_t)ci * taps + td) * Cout + co) = v;
+    }
+  }
+}
+
 // out[c] += sum_m x[m][c]   (bias gradients)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ x, int ldx, float *__restrict__ out,
@@ -768,7 +800,10 @@ extern "C" int cfd_transpose_weight(const void *src, void *dst, int Cout, int ta
   CFD_REQUIRE(src && dst && Cout > 0 && taps > 0 && Cin > 0, "bad arguments");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((Cin + 63) / 64, (Cout + 63) / 64, taps);
-  if (dtype == CFD_BF16)
+  if (dtype == CFD_BF16 && Cin % 8 == 0 && Cout % 8 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0)
+    hipLaunchKernelGGL(transpose_weight_bf16v_kernel, dim3((Cin + 127) / 128, (Cout + 127) / 128, taps), dim3(256), 0, st,
+                       (const bf16 *)src, (bf16 *)dst, Cout, taps, Cin, flip);
+  else if (dtype == CFD_BF16)
     hipLaunchKernelGGL(transpose_weight_kernel<bf16>, grid, dim3(256), 0, st, (const bf16 *)src, (bf16 *)dst, Cout, taps, Cin, flip);
   else if (dtype == CFD_F32)
     hipLaunchKernelGGL(transpose_weight_kernel<float>, grid, dim3(256), 0, st, (const float *)src, (float *)dst, Cout, taps, Cin, flip);

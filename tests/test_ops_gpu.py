@@ -93,6 +93,26 @@ def test_conv_forward(kind, B, H, W, cin, cout, dtype):
     ("k4s1", 1, 4, 32, 64, 128, 16),      # one K tile per slice
 ])
 def test_conv_forward_igemm256(kind, B, H, W, cin, cout, split_k, dtype, pd):
+    _igemm256_case(kind, B, H, W, cin, cout, split_k, dtype, pd)
+
+
+@pytest.mark.parametrize("pd", [36, 37])
+@pytest.mark.parametrize("kind,B,H,W,cin,cout,split_k", [
+    ("k4s2", 4, 32, 128, 64, 512, 1),     # 32 tiles of 16 K tiles: 4 per workgroup on 8 workgroups, 1 on 32
+    ("convT", 2, 16, 32, 128, 256, 1),    # 16 tiles (4 sub-pixel classes), 8 K tiles each
+    ("k3s1", 2, 16, 64, 128, 256, 1),     # 9 taps x 2 chunks = 18 K tiles
+    ("k4s2", 2, 16, 64, 128, 512, 2),     # split-K slabs written from the persistent loop
+    ("k4s2", 9, 24, 40, 64, 256, 1),      # 9 tiles, the last one ragged (M = 2160)
+    ("k4s1", 5, 8, 64, 64, 256, 1),       # 10 tiles: XCD ranges of unequal length (two XCDs get 2 tiles)
+    ("dense", 2048, 1, 1, 256, 256, 1),   # dense: 8 tiles of 4 K tiles
+])
+def test_conv_forward_igemm256_persistent(kind, B, H, W, cin, cout, split_k, pd):
+    """igemm256p_kernel (persistent tile loop, issue stream running into the next tile), forced on 8 workgroups
+    (pd 37: several tiles per workgroup) and on its production grid (pd 36), against the oracle"""
+    _igemm256_case(kind, B, H, W, cin, cout, split_k, torch.bfloat16, pd)
+
+
+def _igemm256_case(kind, B, H, W, cin, cout, split_k, dtype, pd):
     """the 256x256 ping-pong kernel (igemm256.hip; bf16 and exact-f32 MFMA), forced on, against the oracle; bias +
     LeakyReLU fused, output written into a channel slice of a wider buffer"""
     from cfd_amd import ops
@@ -228,9 +248,10 @@ def test_bn_act(B, H, W, C, drop, dtype):
 
 
 @pytest.mark.parametrize("dtype,force256", [(torch.float32, 0), (torch.float32, 1), (torch.bfloat16, 0),
-                                            (torch.bfloat16, 1)])
+                                            (torch.bfloat16, 1), (torch.bfloat16, 37)])
 @pytest.mark.parametrize("kind,B,H,W,cin,cout,drop", [
     ("k4s2", 3, 32, 32, 64, 256, False),    # 256 output pixels per sample: one tile per sample
+    ("k4s2", 16, 32, 32, 64, 256, False),   # 16 tiles: two per workgroup in the persistent kernel (force256 = 37)
     ("k4s2", 2, 32, 64, 64, 256, False),    # 512 per sample
     ("convT", 2, 16, 16, 64, 256, True),    # class grid 256 per sample, dropout (RNG mode)
     ("k4s2", 2, 32, 32, 64, 128, False),    # Cout = 128: 128-wide n tile in both kernels
@@ -253,7 +274,8 @@ def test_conv_stats_bn_apply(kind, B, H, W, cin, cout, drop, dtype, force256):
     st = {}
     ref = O.batchnorm(pre, p, "l", True, True, st)
     Bo, Ho, Wo, _ = pre.shape
-    ops.set_tuning(ops.TUNE_IGEMM256, force256)
+    ops.set_tuning(ops.TUNE_IGEMM256, 1 if force256 >= 36 else force256)
+    ops.set_tuning(ops.TUNE_IGEMM256_PD, force256 if force256 >= 36 else -1)   # 36 / 37: the persistent kernel
     try:
         stats = (torch.zeros((B, cout), device=dev), torch.zeros((B, cout), device=dev))
         raw = torch.empty(tuple(pre.shape), dtype=torch.float32, device=dev)
@@ -261,6 +283,7 @@ def test_conv_stats_bn_apply(kind, B, H, W, cin, cout, drop, dtype, force256):
                                     split_k=1)
     finally:
         ops.set_tuning(ops.TUNE_IGEMM256, -1)
+        ops.set_tuning(ops.TUNE_IGEMM256_PD, -1)
     assert fused, "shape was expected to be fusable"
     n = Ho * Wo
     torch.cuda.synchronize()

@@ -327,3 +327,18 @@ def test_dropout_apply_matches_mask():
     ops.dropout_apply(x, y, 0.5, seed=9, elem0=0)
     m = ops.dropout_mask((4, 1, 1, 256), 0.5, 9).view(4, 256)
     assert torch.equal(y, x * m.float() * 2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cout,kh,cin,flip", [(256, 4, 128, False), (72, 3, 40, True), (130, 4, 6, False), (8, 1, 1024, False)])
+def test_transpose_weight_exact(cout, kh, cin, flip, dtype):
+    """[Cout][kh][kw][Cin] -> [Cin][taps'][Cout], taps reversed when flip: a pure permutation, so bit-exact (the bf16
+    16-byte path for channel counts that are multiples of 8, the scalar path otherwise)"""
+    from cfd_amd import ops
+    w = torch.randn((cout, kh, kh, cin), device="cuda").to(dtype)
+    wt = ops.transpose_weight(w, flip)
+    ref = w.reshape(cout, kh * kh, cin)
+    if flip:
+        ref = ref.flip(1)
+    ref = ref.permute(2, 1, 0).contiguous()
+    assert torch.equal(wt.reshape(cin, kh * kh, cout), ref)
