@@ -22,7 +22,24 @@ struct IgemmParams {
   int cpt;             // K tiles per tap = Cin / BKE
   int nblocks;
   float *stat_sum, *stat_sq;   // optional fused BatchNorm statistics [B][Cout] (accumulated with atomics), or NULL
+  int hw_shift, wq_shift;      // log2(Hq*Wq), log2(Wq) when both are powers of two (every reference grid), else -1
 };
+
+// class-grid row m -> (sample, qy, qx); shifts instead of two integer divisions when the grid sides are powers of two
+// (a tile's address set-up and epilogue do this for 8 rows each)
+__device__ __forceinline__ void split_pixel(const IgemmParams &p, int m, int &b, int &qy, int &qx) {
+  if (p.hw_shift >= 0) {
+    b = m >> p.hw_shift;
+    const int rem = m & ((1 << p.hw_shift) - 1);
+    qy = rem >> p.wq_shift;
+    qx = rem & ((1 << p.wq_shift) - 1);
+  } else {
+    b = m / (p.Hq * p.Wq);
+    const int rem = m - b * (p.Hq * p.Wq);
+    qy = rem / p.Wq;
+    qx = rem - qy * p.Wq;
+  }
+}
 
 // tap t of a class -> input-pixel offset (dy,dx) relative to the class-grid pixel * stride, and the
 // weight tap index; uniform (scalar) arithmetic

@@ -75,9 +75,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const int m = m0 + R;
     mval[i] = m < p.M;
     const int mm = mval[i] ? m : 0;
-    const int b = mm / (p.Hq * p.Wq);
-    const int rem = mm - b * (p.Hq * p.Wq);
-    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    int b, qy, qx;
+    split_pixel(p, mm, b, qy, qx);
     ybase[i] = qy * S;
     xbase[i] = qx * S;
     pix0[i] = (b * p.Hi + qy * S) * p.Wi + qx * S;
@@ -214,9 +213,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + wm * 64 + j * 16 + fr;
     if (m >= p.M) continue;
-    const int b = m / (p.Hq * p.Wq);
-    const int rem = m - b * (p.Hq * p.Wq);
-    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    int b, qy, qx;
+    split_pixel(p, m, b, qy, qx);
     int64_t opix;
     if (p.kind == CFD_CONVT_K4S2)
       opix = ((int64_t)b * p.Ho + 2 * qy + ph) * p.Wo + 2 * qx + pw;
@@ -318,6 +316,12 @@ static int fill_params(const cfd_conv_desc *d, IgemmParams &p) {
   const int64_t M = (int64_t)d->B * p.Hq * p.Wq;
   CFD_REQUIRE(M < (1LL << 31) && (int64_t)d->B * d->Hi * d->Wi < (1LL << 31), "too many pixels");
   p.M = (int)M;
+  {
+    const int hw = p.Hq * p.Wq;
+    const bool pow2 = (hw & (hw - 1)) == 0 && (p.Wq & (p.Wq - 1)) == 0;
+    p.hw_shift = pow2 ? __builtin_ctz((unsigned)hw) : -1;
+    p.wq_shift = pow2 ? __builtin_ctz((unsigned)p.Wq) : -1;
+  }
   p.mtiles = cdiv(M, 128);
   p.ntiles = cdiv(d->Cout, 128);
   p.cpt = d->Cin / bke;

@@ -141,9 +141,8 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
     const int m = m0 + (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow;
     const bool mv = m < p.M;
     const int mm = mv ? m : 0;
-    const int b = mm / (p.Hq * p.Wq);
-    const int rem = mm - b * (p.Hq * p.Wq);
-    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    int b, qy, qx;
+    split_pixel(p, mm, b, qy, qx);
     const int y0 = qy * S, x0 = qx * S;
     rowoff[r] = (unsigned)((((b * p.Hi + y0) * p.Wi + x0) * p.ldx + chunk * EPC) * ES);
     vmask[r] = tap_mask(P.tgeo[cls], y0, x0, p.Hi, p.Wi, mv);
@@ -387,9 +386,8 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fr;
     if (m >= p.M) continue;
-    const int b = m / (p.Hq * p.Wq);
-    const int rem = m - b * (p.Hq * p.Wq);
-    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    int b, qy, qx;
+    split_pixel(p, m, b, qy, qx);
     int64_t opix;
     if (p.kind == CFD_CONVT_K4S2)
       opix = ((int64_t)b * p.Ho + 2 * qy + ph) * p.Wo + 2 * qx + pw;
@@ -436,7 +434,6 @@ constexpr int PART_BYTES = 2 * 4 * 256 * 4;
 __global__ __launch_bounds__(512, 2) void igemm256p_kernel(Igemm256Params P) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const IgemmParams &p = P.g;
-  typedef bf16 T;
   constexpr int ES = 2, EPC = 8, BKE = 64, PD = 6;
   typedef bf16x8 frag_t;
 
@@ -501,9 +498,8 @@ __global__ __launch_bounds__(512, 2) void igemm256p_kernel(Igemm256Params P) {
       const int m = m0 + (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow;
       const bool mv = m < p.M;
       const int mm = mv ? m : 0;
-      const int b = mm / (p.Hq * p.Wq);
-      const int rem = mm - b * (p.Hq * p.Wq);
-      const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+      int b, qy, qx;
+      split_pixel(p, mm, b, qy, qx);
       const int y0 = qy * S, x0 = qx * S;
       rowoff[r] = (unsigned)((((b * p.Hi + y0) * p.Wi + x0) * p.ldx + chunk * EPC) * ES);
       vmask[r] = tap_mask(P.tgeo[cls], y0, x0, p.Hi, p.Wi, mv);
@@ -658,9 +654,8 @@ __global__ __launch_bounds__(512, 2) void igemm256p_kernel(Igemm256Params P) {
     for (int j = 0; j < 4; ++j) {
       const int m = m0 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fr;
       if (m >= p.M) continue;
-      const int b = m / (p.Hq * p.Wq);
-      const int rem = m - b * (p.Hq * p.Wq);
-      const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+      int b, qy, qx;
+      split_pixel(p, m, b, qy, qx);
       int64_t opix;
       if (p.kind == CFD_CONVT_K4S2)
         opix = ((int64_t)b * p.Ho + 2 * qy + ph) * p.Wo + 2 * qx + pw;
@@ -752,9 +747,8 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
     const int m = m0 + (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow;
     const bool mv = m < p.M;
     const int mm = mv ? m : 0;
-    const int b = mm / (p.Hq * p.Wq);
-    const int rem = mm - b * (p.Hq * p.Wq);
-    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    int b, qy, qx;
+    split_pixel(p, mm, b, qy, qx);
     const int y0 = qy * S, x0 = qx * S;
     rowoff[r] = (unsigned)((((b * p.Hi + y0) * p.Wi + x0) * p.ldx + chunk * EPC) * ES);
     vmask[r] = tap_mask(P.tgeo[cls], y0, x0, p.Hi, p.Wi, mv);
@@ -886,9 +880,8 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + wc * 64 + j * 16 + fr;
     if (m >= p.M) continue;
-    const int b = m / (p.Hq * p.Wq);
-    const int rem = m - b * (p.Hq * p.Wq);
-    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    int b, qy, qx;
+    split_pixel(p, m, b, qy, qx);
     int64_t opix;
     if (p.kind == CFD_CONVT_K4S2)
       opix = ((int64_t)b * p.Ho + 2 * qy + ph) * p.Wo + 2 * qx + pw;
