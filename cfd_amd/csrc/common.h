@@ -63,6 +63,14 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   }
 }
 
+// NONE / RELU / LEAKY as one branch-free form max(v,0) + ns * min(v,0) with ns = 1 / 0 / slope: the GEMM epilogues run
+// it on 128 accumulators per lane, where a per-element switch on a run-time `act` compiled to ~700 scalar branches per
+// wave (most of the 7.5 K tiles' worth of time an output tile's epilogue took).  Bit-identical to apply_act for finite v.
+__device__ __forceinline__ float act_neg_scale(int act, float slope) {
+  return act == CFD_ACT_LEAKY ? slope : (act == CFD_ACT_RELU ? 0.f : 1.f);
+}
+__device__ __forceinline__ float apply_act_linear(float v, float ns) { return fmaxf(v, 0.f) + ns * fminf(v, 0.f); }
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 }  // namespace cfd

@@ -111,6 +111,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 
   // ---- accumulators: wave tile 64(n) x 64(m) = 4x4 fragments of 16x16
   const int wm = wave & 1, wn = wave >> 1;
+  const float act_ns = act_neg_scale(p.act, p.slope);
+  const bool act_sig = p.act == CFD_ACT_SIGMOID;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -240,7 +242,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
           v += bv;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.slope);
+        for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);
+        if (act_sig) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+        }
         if (p.out_bf16) {
           bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
           *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;

@@ -43,7 +43,16 @@ struct Igemm256Params {
   int cls_fast;              // block order: 1 = the sub-pixel classes of one pixel tile are adjacent blocks
   int tgeo[4][8];            // per class: kw, kh, dy0, dys, dx0, dxs -- the taps form a kh x kw grid, tap t = ky*kw + kx
                              // sits at (dy0 + dys*ky, dx0 + dxs*kx)
+  int stage_out;             // bf16 output tile goes through LDS and leaves as whole 512-B pixel rows
+  int stagger;               // > 0: the first workgroup of every CU starts (blockIdx % 8) * stagger sleep units late
 };
+
+// LDS-staged output (bf16, no split-K): measured with the stamp build, the direct epilogue -- 32 stores per lane, each
+// wave instruction scattering 16 segments of 32 B -- took 7.6 K tiles' worth per tile (~11 us); staged, a wave
+// instruction stores two whole 512-B pixel rows.
+constexpr int OUT_ROW = 528;               // 512 B of channels + 16 B pad (bank spread of the fragment writes)
+constexpr int OUT_OFF = 8192;              // after the statistics partials
+constexpr int OUT_LDS = OUT_OFF + 256 * OUT_ROW;
 
 // validity bits (bit t = tap t reads inside the image) of one class for the pixel whose stride-scaled origin is
 // (y0, x0): 8 compares on the affine tap grid instead of one table load per tap (the address set-up of a tile is
@@ -87,7 +96,7 @@ __device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) {
 // T = bf16: K tile = 64 elements, mfma_f32_16x16x32_bf16.  T = float: K tile = 32 elements, exact-f32
 // mfma_f32_16x16x4f32; a 16-B fragment read then feeds four MFMAs (lane group fq supplies k = 16 s + 4 fq + e
 // on BOTH operands -- any consistent k assignment sums to the same dot product).  Rows are 128 B either way.
-template <typename T, int PD, bool DIAG = false, int NPH = 4>
+template <typename T, int PD, int DIAG = 0, int NPH = 4>
 __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const IgemmParams &p = P.g;
@@ -100,6 +109,23 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  const float act_ns = act_neg_scale(p.act, p.slope);
+  const bool act_any = p.act == CFD_ACT_LEAKY || p.act == CFD_ACT_RELU;   // (uniform)
+  const bool act_sig = p.act == CFD_ACT_SIGMOID;   // (uniform; never set by the nets for these kernels)
+  // DIAG == 2: four stamps per wave (entry, pipeline primed, K loop done, stores issued) + where it ran
+  unsigned long long tg[5] = {0, 0, 0, 0, 0};
+#define CFD_TSTAMP(i)                                                                   \
+  if constexpr (DIAG == 2) {                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tg[i]) :: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+  }
+  CFD_TSTAMP(0)
+  // De-phasing: all CUs start together and run tiles of equal length, so their output bursts (128 KiB per CU) hit
+  // HBM at the same moment and every CU then waits ~11 us for write bandwidth.  Starting the eight XCDs a fraction
+  // of that apart, once, keeps their bursts apart for the rest of the launch.
+  if (P.stagger > 0 && blockIdx.x < 256)
+    for (int i = (int)(blockIdx.x & 7) * P.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(32);
 
   // ---- XCD-aware block remap (bijective)
   int bid = blockIdx.x;
@@ -209,13 +235,14 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   if constexpr (NPH == 2) wait_vmcnt<6>(); else wait_vmcnt<2 * (PD - 2)>();
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // second group runs one barrier behind
+  CFD_TSTAMP(1)
 
   frag_t a[4][2], b0[2][2], b1[2][2];
 
   // diagnostic build only (DIAG): cycle stamps around the four segments of a phase, summed per wave
   unsigned long long dg[5] = {0, 0, 0, 0, 0}, dt0 = 0, dt1 = 0;
 #define CFD_STAMP(dst)                                                                 \
-      if constexpr (DIAG) {                                                            \
+      if constexpr (DIAG == 1) {                                                       \
         __builtin_amdgcn_sched_barrier(0);                                             \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dst) :: "memory");  \
         __builtin_amdgcn_sched_barrier(0);                                             \
@@ -226,19 +253,19 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
       READS                                                                            \
       issue((PH + PD) & 3, (ST + ((PH + PD) >> 2)) & 1);                               \
       if (((PH + PD) & 3) == 3) iss_advance();                                         \
-      CFD_STAMP(dt1) if constexpr (DIAG) { dg[0] += dt1 - dt0; }                       \
+      CFD_STAMP(dt1) if constexpr (DIAG == 1) { dg[0] += dt1 - dt0; }                       \
       wait_vmcnt<2 * (PD - 2)>();                                                      \
-      CFD_STAMP(dt0) if constexpr (DIAG) { dg[1] += dt0 - dt1; }                       \
+      CFD_STAMP(dt0) if constexpr (DIAG == 1) { dg[1] += dt0 - dt1; }                       \
       __builtin_amdgcn_s_barrier();                                                    \
-      CFD_STAMP(dt1) if constexpr (DIAG) { dg[2] += dt1 - dt0; }                       \
+      CFD_STAMP(dt1) if constexpr (DIAG == 1) { dg[2] += dt1 - dt0; }                       \
       __builtin_amdgcn_sched_barrier(0);                                               \
       __builtin_amdgcn_s_setprio(1);                                                   \
       MFMAS                                                                            \
       __builtin_amdgcn_s_setprio(0);                                                   \
       __builtin_amdgcn_sched_barrier(0);                                               \
-      CFD_STAMP(dt0) if constexpr (DIAG) { dg[3] += dt0 - dt1; }                       \
+      CFD_STAMP(dt0) if constexpr (DIAG == 1) { dg[3] += dt0 - dt1; }                       \
       __builtin_amdgcn_s_barrier();                                                    \
-      CFD_STAMP(dt1) if constexpr (DIAG) { dg[4] += dt1 - dt0; }                       \
+      CFD_STAMP(dt1) if constexpr (DIAG == 1) { dg[4] += dt1 - dt0; }                       \
     }
 #define CFD_MFMA(AI, BJ, BREG)                                                         \
       _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
@@ -281,19 +308,19 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
       issue(SLOTA, STA); issue(SLOTB, STB);                                            \
       if (SLOTB == 3) iss_advance();                                                   \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
-      CFD_STAMP(dt1) if constexpr (DIAG) { dg[0] += dt1 - dt0; }                       \
+      CFD_STAMP(dt1) if constexpr (DIAG == 1) { dg[0] += dt1 - dt0; }                       \
       wait_vmcnt<VM>();                                                                \
-      CFD_STAMP(dt0) if constexpr (DIAG) { dg[1] += dt0 - dt1; }                       \
+      CFD_STAMP(dt0) if constexpr (DIAG == 1) { dg[1] += dt0 - dt1; }                       \
       __builtin_amdgcn_s_barrier();                                                    \
-      CFD_STAMP(dt1) if constexpr (DIAG) { dg[2] += dt1 - dt0; }                       \
+      CFD_STAMP(dt1) if constexpr (DIAG == 1) { dg[2] += dt1 - dt0; }                       \
       __builtin_amdgcn_sched_barrier(0);                                               \
       __builtin_amdgcn_s_setprio(1);                                                   \
       MFMAS                                                                            \
       __builtin_amdgcn_s_setprio(0);                                                   \
       __builtin_amdgcn_sched_barrier(0);                                               \
-      CFD_STAMP(dt0) if constexpr (DIAG) { dg[3] += dt0 - dt1; }                       \
+      CFD_STAMP(dt0) if constexpr (DIAG == 1) { dg[3] += dt0 - dt1; }                       \
       __builtin_amdgcn_s_barrier();                                                    \
-      CFD_STAMP(dt1) if constexpr (DIAG) { dg[4] += dt1 - dt0; }                       \
+      CFD_STAMP(dt1) if constexpr (DIAG == 1) { dg[4] += dt1 - dt0; }                       \
     }
 #define CFD_KTILE2(ST)                                                                 \
     CFD_PHASE2(ST, 2, (ST + 1) & 1, 3, (ST + 1) & 1, 8,                                \
@@ -332,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
 #undef CFD_MFMA
 #undef CFD_PHASE
 #undef CFD_STAMP
-  if constexpr (DIAG) {
+  if constexpr (DIAG == 1) {
     // stamps leave the kernel only through the workspace (split_k must be 1): [block][wave][8]
     if (lane == 0 && p.ws) {
       unsigned long long *o = (unsigned long long *)p.ws + ((size_t)blockIdx.x * 8 + wave) * 8;
@@ -340,8 +367,10 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
       o[5] = (unsigned long long)nkt;
     }
   }
+  CFD_TSTAMP(2)
   if (wr == 0) __builtin_amdgcn_s_barrier();
   wait_vmcnt<0>();   // the tail loads must not outlive the workgroup's LDS allocation
+  CFD_TSTAMP(4)
 
   // ---- fused BatchNorm statistics (host guarantees: split_k == 1, the 256 pixel rows of a tile lie in ONE
   // sample and none is ragged): per channel sum and sum of squares of (acc + bias) over the tile's pixels,
@@ -381,6 +410,48 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
     }
   }
 
+  if (P.stage_out) {
+    // ---- staged epilogue: fragments (bias + activation applied, bf16) -> LDS [pixel][channel] -> whole pixel rows
+    __syncthreads();   // every wave's tail LDS-DMA has landed (each waited for its own): the stages are dead
+    char *stg = lds + OUT_OFF;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ml = (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fr;
+        f32x4 v = acc[i][j] + bv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (act_any) v[r] = apply_act_linear(v[r], act_ns);
+        if (act_sig) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+        }
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *(bf16x4 *)(stg + ml * OUT_ROW + nl * 2) = o;
+      }
+    }
+    __syncthreads();
+    const int half = lane >> 5, ck = lane & 31;   // two pixel rows per wave instruction, 32 chunks of 16 B each
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int ml = wave * 32 + it * 2 + half;
+      const int m = m0 + ml;
+      if (m < p.M) {
+        int64_t opix = m;
+        if (p.kind == CFD_CONVT_K4S2) {
+          int b, qy, qx;
+          split_pixel(p, m, b, qy, qx);
+          opix = ((int64_t)b * p.Ho + 2 * qy + ph) * p.Wo + 2 * qx + pw;
+        }
+        const uint4 v = *(const uint4 *)(stg + ml * OUT_ROW + ck * 16);
+        *(uint4 *)(p.y + (opix * p.ldy + n0) * 2 + ck * 16) = v;
+      }
+    }
+  } else {
   // ---- epilogue: lane holds channels n..n+3 (register index) of pixel m
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -403,7 +474,12 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
       }
       if (p.bias) v += *(const f32x4 *)(p.bias + n);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.slope);
+      for (int r = 0; r < 4; ++r)
+          if (act_any) v[r] = apply_act_linear(v[r], act_ns);
+        if (act_sig) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+        }
       if (p.out_bf16) {
         bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
         *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;
@@ -412,6 +488,19 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
       }
     }
   }
+  }
+  if constexpr (DIAG == 2) {
+    CFD_TSTAMP(3)
+    if (lane == 0 && p.split_k == 1 && p.ws) {   // (the workspace is free when there are no split-K slabs)
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned long long *o = (unsigned long long *)p.ws + ((size_t)blockIdx.x * 8 + wave) * 8;
+      for (int i = 0; i < 4; ++i) o[i] = tg[i];
+      o[4] = hw; o[5] = xcc; o[6] = (unsigned long long)nkt; o[7] = tg[4];
+    }
+  }
+#undef CFD_TSTAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -441,6 +530,9 @@ __global__ __launch_bounds__(512, 2) void igemm256p_kernel(Igemm256Params P) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  const float act_ns = act_neg_scale(p.act, p.slope);
+  const bool act_any = p.act == CFD_ACT_LEAKY || p.act == CFD_ACT_RELU;   // (uniform)
+  const bool act_sig = p.act == CFD_ACT_SIGMOID;   // (uniform; never set by the nets for these kernels)
   const int S = (p.kind == CFD_CONV_K4S2) ? 2 : 1;
   const int ktiles = p.ntaps * p.cpt;
 
@@ -671,7 +763,12 @@ __global__ __launch_bounds__(512, 2) void igemm256p_kernel(Igemm256Params P) {
         }
         if (p.bias) v += *(const f32x4 *)(p.bias + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.slope);
+        for (int r = 0; r < 4; ++r)
+          if (act_any) v[r] = apply_act_linear(v[r], act_ns);
+        if (act_sig) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+        }
         if (p.out_bf16) {
           bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
           *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;
@@ -712,6 +809,9 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  const float act_ns = act_neg_scale(p.act, p.slope);
+  const bool act_any = p.act == CFD_ACT_LEAKY || p.act == CFD_ACT_RELU;   // (uniform)
+  const bool act_sig = p.act == CFD_ACT_SIGMOID;   // (uniform; never set by the nets for these kernels)
 
   int bid = blockIdx.x;
   {
@@ -897,7 +997,12 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
       }
       if (p.bias) v += *(const f32x4 *)(p.bias + n);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.slope);
+      for (int r = 0; r < 4; ++r)
+          if (act_any) v[r] = apply_act_linear(v[r], act_ns);
+        if (act_sig) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+        }
       if (p.out_bf16) {
         bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
         *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;
@@ -960,7 +1065,14 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
       CFD_REQUIRE(kh * kw == p.ntaps && P.tapdy[cls][t] == g[2] + g[3] * (t / kw) && P.tapdx[cls][t] == g[4] + g[5] * (t % kw),
                   "taps of kind %d are not an affine grid", p.kind);
   }
-  const size_t shmem = 2 * ST_BYTES;
+  // staged bf16 output: whole-tile kernel only (n tile 256), no split-K, 16-B aligned rows
+  P.stage_out = ntile == 256 && p.out_bf16 && p.split_k == 1 && p.ldy % 8 == 0 && ((uintptr_t)p.y & 15) == 0 &&
+                tuning(CFD_TUNE_STAGED_OUT) != 0;
+  const size_t shmem = P.stage_out ? (size_t)OUT_LDS : (size_t)2 * ST_BYTES;
+  {
+    const int sg = tuning(CFD_TUNE_STAGED_OUT);   // experiment: values >= 10 = stagger units (s_sleep 32 ~ 2048 cycles)
+    P.stagger = (sg >= 10 && p.nblocks > 256) ? sg - 10 : 0;
+  }
   const int pdt = tuning(CFD_TUNE_IGEMM256_PD);
   // persistent form (igemm256p_kernel): bf16, 256-wide n tiles, more tiles than CUs, every K range even
   // (CFD_TUNE_IGEMM256_PD: 36 forces it where legal, 26 forbids it)
@@ -987,7 +1099,7 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
     static bool done_ = false;                                                                                      \
     if (!done_) {                                                                                                   \
       CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<__VA_ARGS__>,                                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)OUT_LDS));                       \
       done_ = true;                                                                                                 \
     }                                                                                                               \
     hipLaunchKernelGGL((igemm256_kernel<__VA_ARGS__>), dim3(p.nblocks), dim3(512), shmem, st, P);                   \
@@ -1002,12 +1114,13 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
     }
     if (dtype == CFD_F32) hipLaunchKernelGGL(igemm128n_kernel<float>, dim3(p.nblocks), dim3(512), shmem3, st, P);
     else hipLaunchKernelGGL(igemm128n_kernel<bf16>, dim3(p.nblocks), dim3(512), shmem3, st, P);
-  } else if (dtype == CFD_F32) CFD_LAUNCH256(float, 6, false, 4);
-  else if (pdt == 126) CFD_LAUNCH256(bf16, 6, true, 2);
-  else if (pdt == 106) CFD_LAUNCH256(bf16, 6, true, 4);
-  else if (pdt == 5) CFD_LAUNCH256(bf16, 5, false, 4);
-  else if (pdt == 6) CFD_LAUNCH256(bf16, 6, false, 4);
-  else CFD_LAUNCH256(bf16, 6, false, 2);
+  } else if (dtype == CFD_F32) CFD_LAUNCH256(float, 6, 0, 4);
+  else if (pdt == 226) CFD_LAUNCH256(bf16, 6, 2, 2);   // tile-stage stamps (scripts/tile_timeline.py)
+  else if (pdt == 126) CFD_LAUNCH256(bf16, 6, 1, 2);
+  else if (pdt == 106) CFD_LAUNCH256(bf16, 6, 1, 4);
+  else if (pdt == 5) CFD_LAUNCH256(bf16, 5, 0, 4);
+  else if (pdt == 6) CFD_LAUNCH256(bf16, 6, 0, 4);
+  else CFD_LAUNCH256(bf16, 6, 0, 2);
 #undef CFD_LAUNCH256
   CFD_LAUNCH_CHECK();
   return CFD_OK;

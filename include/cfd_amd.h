@@ -41,9 +41,11 @@ const char *cfd_last_error(void);
  *   CFD_TUNE_IGEMM256_PD  schedule variant of that kernel (see igemm256.hip; default = two phases per K tile)
  *   CFD_TUNE_WGRAD256     -1 heuristic | 0 never | 1 whenever eligible: the 256x256 ping-pong weight-gradient kernel
  *   CFD_TUNE_CLASS_ORDER  -1 heuristic | 0 class-major | 1 class-interleaved block order of the sub-pixel classes of a
- *                         transposed convolution (interleaved: the four classes of one pixel tile share L2 lines) */
+ *                         transposed convolution (interleaved: the four classes of one pixel tile share L2 lines)
+ *   CFD_TUNE_STAGED_OUT   -1 / 1 on where legal | 0 off: bf16 output tiles of the 256-wide kernel leave through LDS as whole
+ *                         pixel rows instead of 32-B fragments */
 typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_WGRAD256 = 2, CFD_TUNE_CLASS_ORDER = 3,
-               CFD_TUNE_COUNT = 4 } cfd_tuning_key;
+               CFD_TUNE_STAGED_OUT = 4, CFD_TUNE_COUNT = 5 } cfd_tuning_key;
 int cfd_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------
