@@ -219,19 +219,23 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail loads must not outlive the workgroup's LDS allocation
 
-  // ---- store / accumulate: lane holds dW[co = .. + fq*4 + r][ci = .. + fr]
+  // ---- store / accumulate: lane holds dW[co = .. + fq*4 + r][ci = .. + fr].  The destination (dw, this block's slab, or
+  // atomics into dw) is chosen ONCE: a per-element three-way branch here compiled to ~400 scalar branches per wave.
+  float *const dst = p.split_m == 1 ? p.dw : (p.slab ? p.slab + (int64_t)sm * p.dw_elems : p.dw);
+  const bool atomics = p.split_m > 1 && !p.slab;
+  // 32-bit element offsets inside the (< 2^31 element) gradient tensor: one multiply per row, adds after that
+  const int row_stride = p.ntaps * p.Cin;
+  const int base = (co0 + wr * 64 + fq * 4) * row_stride + tap * p.Cin + ci0 + wc * 32 + fr;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ci = ci0 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fr;
+    for (int r = 0; r < 4; ++r) {
+      const int rowoff = base + ((i >> 2) * 128 + (i & 3) * 16 + r) * row_stride;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4 + r;
-        const int64_t idx = ((int64_t)co * p.ntaps + tap) * p.Cin + ci;
-        if (p.split_m == 1) p.dw[idx] = acc[i][j][r];
-        else if (p.slab) p.slab[(int64_t)sm * p.dw_elems + idx] = acc[i][j][r];   // summed by wgrad_slab_reduce
-        else atomicAdd(p.dw + idx, acc[i][j][r]);
+      for (int j = 0; j < 4; ++j) {
+        float *q = dst + rowoff + (j >> 1) * 128 + (j & 1) * 16;
+        if (atomics) atomicAdd(q, acc[i][j][r]);
+        else *q = acc[i][j][r];
       }
     }
 }
@@ -319,6 +323,7 @@ int wgrad256_launch(Wgrad256Params &p, const void *x, const void *dy, float *dw,
   p.split_m = split_m < ktiles ? split_m : ktiles;
   p.nblocks = p.cotiles * p.citiles * p.ntaps * p.split_m;
   p.dw_elems = (int64_t)p.Cout * p.ntaps * p.Cin;
+  CFD_REQUIRE(p.dw_elems < (1LL << 31), "weight tensor too large for 32-bit element offsets");
   p.slab = p.split_m > 1 ? workspace : nullptr;
   const size_t shmem = 2 * WST;
   static bool done = false;
