@@ -54,22 +54,21 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }  // RNE, NaN-safe (v_cvt_pk_bf16_f32)
 
 // activation in fp32
+// NONE / RELU / LEAKY share one select form, v > 0 ? v : v * ns with ns = 1 / 0 / slope (a scalar, loop-invariant
+// choice; NaN-preserving), so a run-time `act` costs one uniform branch (sigmoid) instead of a switch per element
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
-  switch (act) {
-    case CFD_ACT_LEAKY: return v > 0.f ? v : v * slope;
-    case CFD_ACT_RELU: return v > 0.f ? v : 0.f;
-    case CFD_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-    default: return v;
-  }
+  if (act == CFD_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  const float ns = act == CFD_ACT_LEAKY ? slope : (act == CFD_ACT_RELU ? 0.f : 1.f);
+  return v > 0.f ? v : v * ns;
 }
 
-// NONE / RELU / LEAKY as one branch-free form max(v,0) + ns * min(v,0) with ns = 1 / 0 / slope: the GEMM epilogues run
+// NONE / RELU / LEAKY as one branch-free form v > 0 ? v : ns * v with ns = 1 / 0 / slope: the GEMM epilogues run
 // it on 128 accumulators per lane, where a per-element switch on a run-time `act` compiled to ~700 scalar branches per
-// wave (most of the 7.5 K tiles' worth of time an output tile's epilogue took).  Bit-identical to apply_act for finite v.
+// wave (a third of the 7.5 K tiles' worth of time an output tile's epilogue took).
 __device__ __forceinline__ float act_neg_scale(int act, float slope) {
   return act == CFD_ACT_LEAKY ? slope : (act == CFD_ACT_RELU ? 0.f : 1.f);
 }
-__device__ __forceinline__ float apply_act_linear(float v, float ns) { return fmaxf(v, 0.f) + ns * fminf(v, 0.f); }
+__device__ __forceinline__ float apply_act_linear(float v, float ns) { return v > 0.f ? v : v * ns; }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
