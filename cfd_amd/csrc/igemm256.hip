@@ -414,26 +414,28 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
     // ---- staged epilogue: fragments (bias + activation applied, bf16) -> LDS [pixel][channel] -> whole pixel rows
     __syncthreads();   // every wave's tail LDS-DMA has landed (each waited for its own): the stages are dead
     char *stg = lds + OUT_OFF;
+    // two copies of the fragment loop, chosen once: most launches write the raw pre-BatchNorm sum (no activation),
+    // and the host keeps sigmoid layers off this path
+    auto to_lds = [&](auto with_act) {
+      char *wbase = stg + (wc * 32 + fr) * OUT_ROW + (wr * 64 + fq * 4) * 2;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+      for (int i = 0; i < 8; ++i) {
+        const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ml = (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fr;
-        f32x4 v = acc[i][j] + bv;
+        for (int j = 0; j < 4; ++j) {
+          f32x4 v = acc[i][j] + bv;
+          if constexpr (decltype(with_act)::value) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (act_any) v[r] = apply_act_linear(v[r], act_ns);
-        if (act_sig) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+            for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);
+          }
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4 *)(wbase + ((j >> 1) * 128 + (j & 1) * 16) * OUT_ROW + ((i >> 2) * 128 + (i & 3) * 16) * 2) = o;
         }
-        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        *(bf16x4 *)(stg + ml * OUT_ROW + nl * 2) = o;
       }
-    }
+    };
+    if (act_any) to_lds(std::true_type{}); else to_lds(std::false_type{});
     __syncthreads();
     const int half = lane >> 5, ck = lane & 31;   // two pixel rows per wave instruction, 32 chunks of 16 B each
 #pragma unroll 4
@@ -1067,7 +1069,7 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   }
   // staged bf16 output: whole-tile kernel only (n tile 256), no split-K, 16-B aligned rows
   P.stage_out = ntile == 256 && p.out_bf16 && p.split_k == 1 && p.ldy % 8 == 0 && ((uintptr_t)p.y & 15) == 0 &&
-                tuning(CFD_TUNE_STAGED_OUT) != 0;
+                p.act != CFD_ACT_SIGMOID && tuning(CFD_TUNE_STAGED_OUT) != 0;
   const size_t shmem = P.stage_out ? (size_t)OUT_LDS : (size_t)2 * ST_BYTES;
   {
     const int sg = tuning(CFD_TUNE_STAGED_OUT);   // experiment: values >= 10 = stagger units (s_sleep 32 ~ 2048 cycles)
