@@ -454,7 +454,10 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
       }
     }
   } else {
-  // ---- epilogue: lane holds channels n..n+3 (register index) of pixel m
+  // ---- epilogue: lane holds channels n..n+3 (register index) of pixel m.  Three copies (split-K slab / bf16 / f32
+  // output), chosen once per launch instead of per fragment.
+  auto direct_epi = [&](auto mode_c) {
+  constexpr int MODE = decltype(mode_c)::value;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fr;
@@ -470,26 +473,29 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
     for (int i = 0; i < 8; ++i) {
       const int n = n0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
       f32x4 v = acc[i][j];
-      if (p.split_k > 1) {
+      if constexpr (MODE == 0) {          // split-K slab: raw partial sums
         *(f32x4 *)(p.ws + ((int64_t)sk * p.B * p.Ho * p.Wo + opix) * p.Cout + n) = v;
-        continue;
-      }
-      if (p.bias) v += *(const f32x4 *)(p.bias + n);
+      } else {
+        if (p.bias) v += *(const f32x4 *)(p.bias + n);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-          if (act_any) v[r] = apply_act_linear(v[r], act_ns);
+        for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);   // ns = 1: identity
         if (act_sig) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
         }
-      if (p.out_bf16) {
-        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;
-      } else {
-        *(f32x4 *)(p.y + (opix * p.ldy + n) * 4) = v;
+        if constexpr (MODE == 1) {
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;
+        } else {
+          *(f32x4 *)(p.y + (opix * p.ldy + n) * 4) = v;
+        }
       }
     }
   }
+  };
+  if (p.split_k > 1) direct_epi(std::integral_constant<int, 0>{});
+  else if (p.out_bf16) direct_epi(std::integral_constant<int, 1>{});
+  else direct_epi(std::integral_constant<int, 2>{});
   }
   if constexpr (DIAG == 2) {
     CFD_TSTAMP(3)
