@@ -984,6 +984,9 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
     }
   }
 
+  // (output mode chosen once per launch, as in igemm256_kernel)
+  auto direct_epi = [&](auto mode_c) {
+  constexpr int MODE = decltype(mode_c)::value;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + wc * 64 + j * 16 + fr;
@@ -999,26 +1002,29 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
     for (int i = 0; i < 4; ++i) {
       const int n = n0 + wr * 64 + i * 16 + fq * 4;
       f32x4 v = acc[i][j];
-      if (p.split_k > 1) {
+      if constexpr (MODE == 0) {
         *(f32x4 *)(p.ws + ((int64_t)sk * p.B * p.Ho * p.Wo + opix) * p.Cout + n) = v;
-        continue;
-      }
-      if (p.bias) v += *(const f32x4 *)(p.bias + n);
+      } else {
+        if (p.bias) v += *(const f32x4 *)(p.bias + n);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-          if (act_any) v[r] = apply_act_linear(v[r], act_ns);
+        for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);
         if (act_sig) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
         }
-      if (p.out_bf16) {
-        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;
-      } else {
-        *(f32x4 *)(p.y + (opix * p.ldy + n) * 4) = v;
+        if constexpr (MODE == 1) {
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;
+        } else {
+          *(f32x4 *)(p.y + (opix * p.ldy + n) * 4) = v;
+        }
       }
     }
   }
+  };
+  if (p.split_k > 1) direct_epi(std::integral_constant<int, 0>{});
+  else if (p.out_bf16) direct_epi(std::integral_constant<int, 1>{});
+  else direct_epi(std::integral_constant<int, 2>{});
 }
 
 static int64_t x_bytes(const IgemmParams &p, int es) { return (((int64_t)p.B * p.Hi * p.Wi - 1) * p.ldx + p.Cin) * es; }
