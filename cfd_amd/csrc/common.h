@@ -70,6 +70,18 @@ __device__ __forceinline__ float act_neg_scale(int act, float slope) {
 }
 __device__ __forceinline__ float apply_act_linear(float v, float ns) { return v > 0.f ? v : v * ns; }
 
+// activation of a small register vector with the kind decided ONCE (one uniform branch per vector, none per element)
+template <int N>
+__device__ __forceinline__ void apply_act_vec(float (&o)[N], const float (&f)[N], float ns, bool sig) {
+  if (sig) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = 1.f / (1.f + __expf(-f[i]));
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = apply_act_linear(f[i], ns);
+  }
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 }  // namespace cfd

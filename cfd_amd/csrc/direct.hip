@@ -13,13 +13,17 @@ namespace cfd {
 // ((TX-1)*S+KS) cols x CIN) is staged in LDS with zero padding (TF 'same': pad 1 before),
 // each thread keeps the weights of its CPT output channels in registers.
 // ---------------------------------------------------------------------------------------------
+// pixels of one output row per tile: 128 amortises the patch staging and its two barriers over 16 pixels per thread
+// (32 left 4 per thread between barriers)
+constexpr int CONV_FIRST_TX = 128;
+
 template <int KS, int S, int CIN, int CPT, typename TO>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, const float *__restrict__ x2,
                                                          int cin1, const float *__restrict__ w,
                                                          const float *__restrict__ bias, TO *__restrict__ y, int ldy,
                                                          TO *__restrict__ y2, int ldy2, int Hi, int Wi, int Ho, int Wo,
                                                          int Cout, int act, int act2, float slope, int ntiles) {
-  constexpr int TX = 32;
+  constexpr int TX = CONV_FIRST_TX;
   constexpr int PW = (TX - 1) * S + KS;
   constexpr int NW = KS * KS * CIN;
   __shared__ float patch[KS][PW][CIN];
@@ -31,6 +35,10 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
   const int pstep = 256 / CG;
 
   const int xtiles = (Wo + TX - 1) / TX;
+  // activation kinds resolved once (a per-element switch on the run-time `act` compiled to ~6 scalar branches per
+  // output element, next to its 16 FMAs)
+  const float ns1 = act_neg_scale(act, slope), ns2 = act_neg_scale(act2, slope);
+  const bool sig1 = act == CFD_ACT_SIGMOID, sig2 = act2 == CFD_ACT_SIGMOID;
 
   // weights of my channels: wreg[c][tap*CIN + ci] -- loaded ONCE per block; the block then walks many tiles
   // (a per-tile block re-read 128 KB of weights to write 32 KB of output)
@@ -86,14 +94,17 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
           }
       const size_t opix = ((size_t)b * Ho + oy) * Wo + ox;
       TO o[CPT];
+      float fo[CPT];
+      apply_act_vec(fo, accv, ns1, sig1);
 #pragma unroll
-      for (int c = 0; c < CPT; ++c) o[c] = from_f32<TO>(apply_act(accv[c], act, slope));
+      for (int c = 0; c < CPT; ++c) o[c] = from_f32<TO>(fo[c]);
       TO *dst = y + opix * ldy + cg * CPT;
 #pragma unroll
       for (int c = 0; c < CPT; ++c) dst[c] = o[c];  // contiguous CPT elements: the compiler merges into one wide store
       if (y2) {
+        apply_act_vec(fo, accv, ns2, sig2);
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) o[c] = from_f32<TO>(apply_act(accv[c], act2, slope));
+        for (int c = 0; c < CPT; ++c) o[c] = from_f32<TO>(fo[c]);
         TO *dst2 = y2 + opix * ldy2 + cg * CPT;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) dst2[c] = o[c];
@@ -109,7 +120,7 @@ static int launch_conv_first(const float *x, const float *x2, int cin1, const fl
   const int Ho = Hi / S, Wo = Wi / S;
   const int CG = Cout / CPT;
   CFD_REQUIRE(Cout % CPT == 0 && CG <= 256 && 256 % CG == 0, "conv_first: Cout=%d unsupported", Cout);
-  const int ntiles = B * Ho * ((Wo + 31) / 32);
+  const int ntiles = B * Ho * ((Wo + CONV_FIRST_TX - 1) / CONV_FIRST_TX);
   const int blocks = ntiles < 2048 ? ntiles : 2048;
   if (out_dtype == CFD_BF16)
     hipLaunchKernelGGL((conv_first_kernel<KS, S, CIN, CPT, bf16>), dim3(blocks), dim3(256), 0, st, x, x2, cin1, w, bias,

@@ -181,12 +181,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const TI *__restrict__ x, i
       for (int i = 0; i < VN; ++i) f[i] = (((h >> (sh0 + 8 * i)) & 0xff) >= drop_thr) ? f[i] * drop_scale : 0.f;
     }
     float o[VN];
-#pragma unroll
-    for (int i = 0; i < VN; ++i) o[i] = apply_act(f[i], act, slope);
+    apply_act_vec(o, f, act_neg_scale(act, slope), act == CFD_ACT_SIGMOID);
     VecIO<TO, VN>::store(yb + (size_t)p * ldy, o);
     if (y2b) {
-#pragma unroll
-      for (int i = 0; i < VN; ++i) o[i] = apply_act(f[i], act2, slope);
+      apply_act_vec(o, f, act_neg_scale(act2, slope), act2 == CFD_ACT_SIGMOID);
       VecIO<TO, VN>::store(y2b + (size_t)p * ldy2, o);
     }
   }
@@ -254,12 +252,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI *__restrict__ x,
       for (int i = 0; i < 8; ++i) f[i] = (((h >> (8 * i)) & 0xff) >= drop_thr) ? f[i] * drop_scale : 0.f;
     }
     float o[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = apply_act(f[i], act, slope);
+    apply_act_vec(o, f, act_neg_scale(act, slope), act == CFD_ACT_SIGMOID);
     VecIO<TO, 8>::store(yb + (size_t)p * ldy, o);
     if (y2b) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = apply_act(f[i], act2, slope);
+      apply_act_vec(o, f, act_neg_scale(act2, slope), act2 == CFD_ACT_SIGMOID);
       VecIO<TO, 8>::store(y2b + (size_t)p * ldy2, o);
     }
   }
