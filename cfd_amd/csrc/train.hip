@@ -46,12 +46,11 @@ template <> struct IO8<float> {
   }
 };
 
-__device__ __forceinline__ float act_grad(float v, int act, float slope) {  // derivative by the sign of v
-  switch (act) {
-    case CFD_ACT_LEAKY: return v > 0.f ? 1.f : slope;
-    case CFD_ACT_RELU: return v > 0.f ? 1.f : 0.f;
-    default: return 1.f;
-  }
+// derivative by the sign of v: 1 above zero, else slope / 0 / 1 for LEAKY / RELU / none -- the scalar choice is
+// loop-invariant, so a run-time `act` costs one compare + select per element instead of a switch
+__device__ __forceinline__ float act_grad(float v, int act, float slope) {
+  const float ns = act == CFD_ACT_LEAKY ? slope : (act == CFD_ACT_RELU ? 0.f : 1.f);
+  return v > 0.f ? 1.f : ns;
 }
 
 // ---------------------------------------------------------------------------------------------
