@@ -50,6 +50,7 @@ SIGNATURES = {
     "cfd_bn_apply": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, C.c_uint64, _i64, _vp, _i, _vp, _i, _i, _i,
                           _i, _f, _i, _i, _f, _i, _vp]),
     "cfd_dropout_epoch": (_i, [C.c_uint64, _i, _vp]),
+    "cfd_bn_stats": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "cfd_dropout_mask": (_i, [_vp, _i64, _i, _i, _i, _f, C.c_uint64, _vp]),
     "cfd_maxpool2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cfd_cast_copy": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),

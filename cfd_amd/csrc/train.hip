@@ -711,7 +711,10 @@ static int bn_act_bwd_impl(const void *x, int ldx, int x_dtype, const float *mea
   const unsigned thr = (drop_mask || drop_rate == 0.f) ? 0u : drop_threshold2(drop_rate);
   hipStream_t st = (hipStream_t)stream;
   // large tensors with a sums workspace: two coalesced, chip-filling passes
-  if (sums && C >= 64 && C / 8 <= 256 && 256 % (C / 8) == 0 && (int64_t)B * HW * C >= (1 << 22)) {
+  // (also at small batch: the one-pass kernel runs one block per (sample, 64 channels), 8 blocks for a 512-channel
+  //  tensor at batch 1)
+  const bool big = (int64_t)B * HW * C >= (1 << 22) || ((int64_t)HW * C >= (1 << 18) && B * (C / 64) < 128);
+  if (sums && C >= 64 && C / 8 <= 256 && 256 % (C / 8) == 0 && big) {
     const int rpar = 256 / (C / 8);
     int ppc = rpar * 16;
     if (ppc > HW) ppc = HW;

@@ -39,6 +39,7 @@ DROP_RATE = 0.5
 # elements per sample: those tensors cost little bandwidth and rounding them BEFORE the mean is
 # subtracted is the largest single error term of the bf16 path.  Larger (high-resolution) layers keep bf16.
 RAW_F32_MAX_ELEMS = 524288
+BN_SPLIT_MIN_ELEMS = 1 << 18      # per-sample tensor size from which BatchNorm statistics get their own chip-wide pass
 
 
 def _bn_specs(name: str, c: int) -> List[Spec]:
@@ -94,6 +95,12 @@ class _Net:
         mean = self.buf(pl, "mean_" + name, (B, f), torch.float32)
         var = self.buf(pl, "var_" + name, (B, f), torch.float32)
         g, b = P.m(name + ".bn.gamma"), P.m(name + ".bn.beta")
+        _B, h, w, _c = raw.shape
+        if not fused and f % 64 == 0 and 2048 % f == 0 and h * w * f >= BN_SPLIT_MIN_ELEMS and B * (f // 64) < 128:
+            # small batch, large layer (the conv ran split-K, so its epilogue could not take the statistics): a
+            # pixel-parallel statistics pass instead of bn_act's one block per (sample, 64 channels)
+            ops.bn_stats(raw, st[name])
+            fused = True
         if fused:
             ops.bn_apply(raw, st[name], g, b, act, out=out, mean=mean, var=var, eps=BN_EPS, **kw)
         else:

@@ -319,6 +319,16 @@ def bn_apply(x: torch.Tensor, stats: Tuple[torch.Tensor, torch.Tensor], gamma: t
     return out
 
 
+def bn_stats(x: torch.Tensor, stats: Tuple[torch.Tensor, torch.Tensor]) -> None:
+    """accumulate per-sample (sum, sumsq) of x [B,H,W,C] into the zeroed fp32 (B, C) buffers `stats` (for bn_apply)"""
+    B, H, W, Cc = x.shape
+    xp, ldx = _nhwc(x)
+    _numel(stats[0], B * Cc, "stats sum", torch.float32)
+    _numel(stats[1], B * Cc, "stats sumsq", torch.float32)
+    check(_lib.load().cfd_bn_stats(xp, ldx, _DT[x.dtype], _ptr(stats[0]), _ptr(stats[1]), B, H * W, Cc, _stream()),
+          "cfd_bn_stats")
+
+
 def dropout_epoch(value: int, set_: bool = False) -> None:
     """advance (or set) the device-resident dropout epoch on the current stream (see cfd_dropout_epoch)"""
     check(_lib.load().cfd_dropout_epoch(int(value), int(set_), _stream()), "cfd_dropout_epoch")

@@ -148,6 +148,10 @@ int cfd_bn_apply(const void *x, int ldx, int x_dtype, const float *stat_sum, con
                  const float *beta, float *mean, float *var, const uint8_t *drop_mask, float drop_rate,
                  uint64_t drop_seed, int64_t sample0, void *y, int ldy, void *y2, int ldy2, int B, int HW, int C,
                  float eps, int act, int act2, float leaky_slope, int dtype, void *stream);
+/* Per-sample statistics for cfd_bn_apply when the producing conv could not fuse them (split-K): accumulates
+ * sum / sum of squares of x [B][HW][C] into stat_sum / stat_sq fp32 [B][C] (zeroed by the caller), pixel-parallel.
+ * Replaces the first pass of BatchNormalization(training=True) (generator.py:20,33).  C in {64,128,...,2048}. */
+int cfd_bn_stats(const void *x, int ldx, int x_dtype, float *stat_sum, float *stat_sq, int B, int HW, int C, void *stream);
 /* Device-resident dropout epoch (no counterpart in the reference): forward kernels in RNG mode whose drop_seed has
  * bit 63 set use seed + epoch * odd_constant.  set != 0: epoch = value; else epoch += value.  Lets a captured HIP
  * graph (whose kernel arguments are frozen) draw fresh dropout per replay.  Seeds below 2^63 ignore the epoch, so a

@@ -100,12 +100,16 @@ def test_dp_world2_equals_one_process_on_both_samples():
     assert vw.calls[0] == vw.calls[1] and len(vw.calls[0]) >= 6      # D x2, D-BN, >= 2 buckets of G, moving stats
     ref = _make()
     _step(*ref, xs, us, sample0=0)
-    for name, k in (("G", 0), ("D", 1)):
+    # Adam's first step moves a weight by ~lr * sign(g): an element whose near-zero gradient changes sign between two
+    # fp32 summation orders (the ranks run batch 1, the reference batch 2: different split-K and atomics order) lands
+    # 2 * lr away.  So: nothing further than that, and almost no element further than lr / 2.
+    for name, k, lr in (("G", 0, 4e-4), ("D", 1, 2e-3)):
         w_ref = ref[k].params
         for rank in range(2):
             P = ranks[rank][k].params
             n = P.n_trainable      # kernels, biases, BatchNorm gamma / beta
-            err = float((P.master[:n] - w_ref.master[:n]).abs().max())
-            assert err <= 2e-4 * float(w_ref.master[:n].abs().max()), (name, rank, err)
+            diff = (P.master[:n] - w_ref.master[:n]).abs()
+            assert float(diff.max()) <= 2.5 * lr, (name, rank, float(diff.max()))
+            assert float((diff > 0.5 * lr).double().mean()) <= 1e-3, (name, rank)
         # both ranks hold the same state bit for bit, D's rank-averaged moving statistics included
         assert torch.equal(ranks[0][k].params.master, ranks[1][k].params.master), name

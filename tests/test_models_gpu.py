@@ -72,7 +72,8 @@ def test_generator_rng_dropout_matches_exported_mask(dtype):
     keep = float(torch.stack([m.float().mean() for m in masks]).mean())
     assert 0.49 < keep < 0.51
     y_mask = g.forward(xd, masks=masks)
-    assert torch.equal(y_rng, y_mask)
+    # same mask -> same result up to the commit order of the fp32 atomics that accumulate the BatchNorm statistics
+    assert relerr(y_rng.cpu(), y_mask.cpu()) <= (1e-5 if dtype == torch.float32 else 1e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

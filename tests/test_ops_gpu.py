@@ -402,3 +402,25 @@ def test_eval_metrics(H, W):
     assert np.isnan(m[2, 3])
     e, _ = ops.eval_metrics(torch.zeros((0, H, W), device="cuda"), torch.zeros((0, H, W), device="cuda"))
     assert e.shape == (0, 4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [(1, 16, 128, 512), (2, 7, 9, 64), (3, 4, 32, 2048)])
+def test_bn_stats_then_apply(B, H, W, C, dtype):
+    """pixel-parallel statistics pass (cfd_bn_stats) + bn_apply == oracle BatchNorm with per-sample batch statistics:
+    the small-batch route for layers whose conv ran split-K"""
+    from cfd_amd import ops
+    dev = "cuda"
+    x = q(rnd((B, H, W, C), 1) * 0.7 + 0.3, dtype)
+    p = {"l.bn.gamma": 1 + 0.1 * rnd((C,), 2), "l.bn.beta": 0.1 * rnd((C,), 3)}
+    st = {}
+    ref = O.batchnorm(x, p, "l", True, True, st)
+    stats = (torch.zeros((B, C), device=dev), torch.zeros((B, C), device=dev))
+    xd = x.to(dev).to(dtype)
+    ops.bn_stats(xd, stats)
+    mean, var = torch.empty((B, C), device=dev), torch.empty((B, C), device=dev)
+    y = ops.bn_apply(xd, stats, p["l.bn.gamma"].to(dev), p["l.bn.beta"].to(dev), ops.ACT_LEAKY, mean=mean, var=var)
+    torch.cuda.synchronize()
+    assert relerr(stats[0].cpu() / (H * W), st["l"][0]) <= 2e-5
+    assert relerr(mean.cpu(), st["l"][0]) <= 2e-5 and relerr(var.cpu(), st["l"][1]) <= 2e-4
+    assert relerr(y.float().cpu(), O.leaky(ref)) <= TOL[dtype]

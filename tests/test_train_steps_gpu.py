@@ -243,13 +243,18 @@ def test_pipelined_step_equals_reference_order():
         res = {}
         c = gtr2.train_on_batch(x, 1.0, u, seed=2 * step + 1, before_d=lambda: res.setdefault("b", dtr2.finish()))
         out2.append([a, res["b"]] + c)
-    assert np.allclose(out1, out2, rtol=1e-4, atol=1e-6), (out1, out2)
+    # first step: same arithmetic up to atomics order; second step: downstream of Adam's sign-sensitive first update
+    assert np.allclose(out1[0], out2[0], rtol=1e-5, atol=1e-6), (out1, out2)
+    assert np.allclose(out1[1], out2[1], rtol=2e-3, atol=1e-5), (out1, out2)
     # Weights: the two orders run the same kernels on the same data, but the fp32 atomics inside them commit in a
     # different order from run to run, and Adam's first steps move every weight by ~lr * sign(g): an element whose
     # near-zero gradient changes sign lands 2 * lr away.  So: no element further than two such flips, and few flips.
     for n1, n2, lr in ((g1, g2, 4e-4), (d1, d2, 2e-3)):
-        diff = (n1.params.master - n2.params.master).abs()
+        n = n1.params.n_trainable
+        diff = (n1.params.master[:n] - n2.params.master[:n]).abs()
         assert float(diff.max()) <= 4.5 * lr, float(diff.max())
         assert float((diff > 0.5 * lr).double().mean()) <= 1e-3
+        # moving statistics (D): relative, they scale with the activations
+        assert rel_l2(n1.params.master[n:], n2.params.master[n:]) <= 1e-3 or n1.params.master[n:].numel() == 0
     with pytest.raises(RuntimeError):
         dtr2.finish()
