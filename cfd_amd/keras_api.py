@@ -37,20 +37,22 @@ def _dtype() -> torch.dtype:
         os.environ.get("CFD_AMD_DTYPE", "bf16").lower()]
 
 
-GRAPH_MAX_BATCH = 8     # largest batch whose predict may be replayed as one captured HIP graph (CFD_AMD_GRAPHS=1)
+GRAPH_MAX_BATCH = 8     # largest batch whose predict is replayed as one captured HIP graph (CFD_AMD_GRAPHS=0 turns it off)
 
 
 class _GraphedForward:
     """One captured HIP graph of `net.forward` for a fixed batch size: the per-case predict loop of the reference
-    (utils.py:55-58, U/valid.py:25-35) issues ~80 kernels per case.  Measured at batch 1 the replay saves only ~1-3 %
-    (0.79 vs 0.80 ms for U: the small layers are latency-bound on the GPU, not on the host), so it is opt-in.  The
-    graph starts with the dropout-epoch kernel so that every replay draws fresh dropout."""
+    (utils.py:55-58, U/valid.py:25-35) issues ~80 kernels per case, and at batch 1 the host is the slower side: U
+    0.64 ms eager, 0.48 ms replayed (P 0.59 -> 0.39).  The graph starts with the dropout-epoch kernel so that every
+    replay draws fresh dropout.  Weights are read in place (loading and training update the same buffers), and the
+    graph keeps the shared workspace it was captured with alive."""
 
     def __init__(self, net, x: torch.Tensor, **fwd):
         self.x = x.clone()
         net.forward(self.x, **fwd)                     # warm-up: buffers, function attributes, workspace
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        self.keep = list(ops._ws_cache.values())       # the grow-only workspace may be replaced later: hold this one
         with torch.cuda.graph(self.graph):
             ops.dropout_epoch(1)
             self.y = net.forward(self.x, **fwd)
@@ -62,7 +64,7 @@ class _GraphedForward:
 
 
 def _use_graphs() -> bool:
-    return os.environ.get("CFD_AMD_GRAPHS", "0") == "1"
+    return os.environ.get("CFD_AMD_GRAPHS", "1") != "0"
 
 
 def _dev(a) -> torch.Tensor:
