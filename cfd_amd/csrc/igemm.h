@@ -25,6 +25,13 @@ struct IgemmParams {
   int hw_shift, wq_shift;      // log2(Hq*Wq), log2(Wq) when both are powers of two (every reference grid), else -1
 };
 
+// first K tile of split-K slice sk (slice = [k_slice(sk), k_slice(sk + 1))): ktiles * sk < 2^31 (host: ktiles <= 16 taps *
+// Cin / 32, split_k <= ktiles), so 32-bit arithmetic -- a 64-bit division is ~150 instructions in every tile's set-up;
+// no division at all without split-K
+__device__ __forceinline__ int k_slice(int ktiles, int sk, int split_k) {
+  return split_k == 1 ? ktiles * sk : (int)((unsigned)(ktiles * sk) / (unsigned)split_k);
+}
+
 // class-grid row m -> (sample, qy, qx); shifts instead of two integer divisions when the grid sides are powers of two
 // (a tile's address set-up and epilogue do this for 8 rows each)
 __device__ __forceinline__ void split_pixel(const IgemmParams &p, int m, int &b, int &qy, int &qx) {

@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   const char *zero = (const char *)g_zero_page;
 
   const int ktiles = p.ntaps * p.cpt;
-  const int kbeg = (int)((int64_t)ktiles * sk / p.split_k);
-  const int kend = (int)((int64_t)ktiles * (sk + 1) / p.split_k);
+  const int kbeg = k_slice(ktiles, sk, p.split_k);
+  const int kend = k_slice(ktiles, sk + 1, p.split_k);
 
   auto stage = [&](int kt, int buf) {
     const int t = kt / p.cpt;

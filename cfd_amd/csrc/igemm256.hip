@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   const bool act_any = p.act == CFD_ACT_LEAKY || p.act == CFD_ACT_RELU;   // (uniform)
   const bool act_sig = p.act == CFD_ACT_SIGMOID;   // (uniform; never set by the nets for these kernels)
   // DIAG == 2: four stamps per wave (entry, pipeline primed, K loop done, stores issued) + where it ran
-  unsigned long long tg[5] = {0, 0, 0, 0, 0};
+  unsigned long long tg[6] = {0, 0, 0, 0, 0, 0};
 #define CFD_TSTAMP(i)                                                                   \
   if constexpr (DIAG == 2) {                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                  \
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   const int S = (p.kind == CFD_CONV_K4S2) ? 2 : 1;
 
   const int ktiles = p.ntaps * p.cpt;
-  const int kbeg = (int)((int64_t)ktiles * sk / p.split_k);
-  const int kend = (int)((int64_t)ktiles * (sk + 1) / p.split_k);
+  const int kbeg = k_slice(ktiles, sk, p.split_k);
+  const int kend = k_slice(ktiles, sk + 1, p.split_k);
   const int nkt = kend - kbeg;
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)P.xbytes, 0x00020000);
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
 
   // ---- issue stream state (uniform): the K tile whose half tiles are being issued
   int iss_left = nkt;                       // K tiles not yet fully issued (incl. the current one)
-  int iss_t = kbeg / p.cpt, iss_c = kbeg - iss_t * p.cpt;
+  int iss_t = kbeg ? kbeg / p.cpt : 0, iss_c = kbeg - iss_t * p.cpt;
   unsigned s_a = 0, s_b = 0;                // scalar byte offsets: A = (wtap*Cin + c*64)*2, B = c*128
   auto tap_switch = [&]() {
     const int info = P.tapinfo[cls][iss_t];
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  CFD_TSTAMP(5)
   // ---- prologue: H0 .. H(PD-1)   (NPH == 2: H0 .. H5, and H0..H2 must have landed)
   constexpr int PRO = NPH == 2 ? 6 : PD;
 #pragma unroll
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       unsigned long long *o = (unsigned long long *)p.ws + ((size_t)blockIdx.x * 8 + wave) * 8;
       for (int i = 0; i < 4; ++i) o[i] = tg[i];
-      o[4] = hw; o[5] = xcc; o[6] = (unsigned long long)nkt; o[7] = tg[4];
+      o[4] = hw; o[5] = (unsigned long long)xcc | (tg[5] << 8); o[6] = (unsigned long long)nkt; o[7] = tg[4];
     }
   }
 #undef CFD_TSTAMP
@@ -584,8 +585,8 @@ __global__ __launch_bounds__(512, 2) void igemm256p_kernel(Igemm256Params P) {
     int nt, mt, cls, sk;
     decode(id, nt, mt, cls, sk);
     iss_cls = __builtin_amdgcn_readfirstlane(cls);
-    const int kbeg = (int)((int64_t)ktiles * sk / p.split_k);
-    const int kend = (int)((int64_t)ktiles * (sk + 1) / p.split_k);
+    const int kbeg = k_slice(ktiles, sk, p.split_k);
+    const int kend = k_slice(ktiles, sk + 1, p.split_k);
     iss_left = __builtin_amdgcn_readfirstlane(kend - kbeg);
     iss_t = __builtin_amdgcn_readfirstlane(kbeg / p.cpt);
     iss_c = __builtin_amdgcn_readfirstlane(kbeg - iss_t * p.cpt);
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void igemm256p_kernel(Igemm256Params P) {
     const int ph = cls >> 1, pw = cls & 1;
     const int m0 = mt * 256, n0 = nt * 256;
     const int nkt = __builtin_amdgcn_readfirstlane(
-        (int)((int64_t)ktiles * (sk + 1) / p.split_k) - (int)((int64_t)ktiles * sk / p.split_k));
+        k_slice(ktiles, sk + 1, p.split_k) - k_slice(ktiles, sk, p.split_k));
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -836,8 +837,8 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
   const int S = (p.kind == CFD_CONV_K4S2) ? 2 : 1;
 
   const int ktiles = p.ntaps * p.cpt;
-  const int kbeg = (int)((int64_t)ktiles * sk / p.split_k);
-  const int kend = (int)((int64_t)ktiles * (sk + 1) / p.split_k);
+  const int kbeg = k_slice(ktiles, sk, p.split_k);
+  const int kend = k_slice(ktiles, sk + 1, p.split_k);
   const int nkt = kend - kbeg;
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)P.xbytes, 0x00020000);
@@ -863,7 +864,7 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
   }
 
   int iss_left = nkt;
-  int iss_t = kbeg / p.cpt, iss_c = kbeg - iss_t * p.cpt;
+  int iss_t = kbeg ? kbeg / p.cpt : 0, iss_c = kbeg - iss_t * p.cpt;
   unsigned s_a = 0, s_b = 0;
   auto tap_switch = [&]() {
     const int info = P.tapinfo[cls][iss_t];

@@ -33,13 +33,16 @@ assert (t[..., 0] > 0).all(), "some workgroup did not write its stamps"
 t0 = t[..., 0].min()
 span = (t[..., 3].max() - t0)
 tick_us = kernel_us / span            # s_memtime ticks -> us, from the kernel's own duration
-st = ((t[..., 1] - t[..., 0]).mean(), (t[..., 2] - t[..., 1]).mean(), (t[..., 7] - t[..., 2]).mean(),
+t5 = t[..., 5] >> 8                     # stamp after the address set-up (packed above the XCC id)
+low = t[..., 0] & ((1 << 55) - 1)
+setup = ((t5 - low) & ((1 << 55) - 1)).mean()
+st = (setup, (t[..., 1] - t[..., 0]).mean() - setup, (t[..., 2] - t[..., 1]).mean(), (t[..., 7] - t[..., 2]).mean(),
       (t[..., 3] - t[..., 7]).mean())
 nkt = int(t[0, 0, 6])
 print(f"cin {cin}: {nblocks} tiles, {nkt} K tiles each, kernel {kernel_us:.1f} us, {span} ticks ({1/tick_us:.0f} ticks/us)")
-per_k = st[1] * tick_us / nkt
-for name, v in zip(("entry -> pipeline primed (set-up + prologue)", "K loop", "K loop done -> tail loads drained (vmcnt 0)",
-                    "bias / activation / convert + stores issued"), st):
+per_k = st[2] * tick_us / nkt
+for name, v in zip(("entry -> addresses set up", "first loads issued -> pipeline primed", "K loop",
+                    "K loop done -> tail loads drained (vmcnt 0)", "bias / activation / convert + stores issued"), st):
     print(f"   {name:48s} {v * tick_us:8.2f} us  = {v * tick_us / per_k:6.1f} K tiles")
 # gaps on one CU: group workgroups by (xcc, hw_id CU/SE bits), sort by entry
 hw, xcc = t[:, 0, 4], t[:, 0, 5] & 0xf
