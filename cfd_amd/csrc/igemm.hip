@@ -89,23 +89,37 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   const int kbeg = k_slice(ktiles, sk, p.split_k);
   const int kend = k_slice(ktiles, sk + 1, p.split_k);
 
-  auto stage = [&](int kt, int buf) {
-    const int t = kt / p.cpt;
-    const int ci0 = (kt - t * p.cpt) * BKE;
+  // K tiles are staged strictly in order, so the (tap, channel chunk) position is a pair of counters, and everything
+  // that depends on the tap only -- geometry, the in-image test, the 64-bit row pointers -- is computed at a tap
+  // switch; a K tile then costs one add per pointer (this kernel has only 32 MFMAs per wave per K tile to hide
+  // its address arithmetic behind)
+  int st_t = kbeg / p.cpt, st_c = kbeg - st_t * p.cpt;
+  const char *xrow[4], *wtap_row[4];
+  auto tap_setup = [&]() {
     int dy, dx, wtap;
-    tap_geom(p.kind, ph, pw, t, dy, dx, wtap);
-    char *wdst = lds + buf * STAGE_BYTES + wave * 1024;
-    char *xdst = wdst + TILE_BYTES;
-    const int64_t woff = ((int64_t)wtap * p.Cin + ci0) * ES;
-    const int xoff = ci0 + chunk * EPC;
+    tap_geom(p.kind, ph, pw, st_t, dy, dx, wtap);
+    const int64_t woff = (int64_t)wtap * p.Cin * ES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const char *ws = wrow[i] ? wrow[i] + woff : zero;
-      glds16(ws, wdst + i * 4096);
+      wtap_row[i] = wrow[i] ? wrow[i] + woff : nullptr;
       const int iy = ybase[i] + dy, ix = xbase[i] + dx;
       const bool ok = mval[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      const char *xs = ok ? p.x + ((int64_t)(pix0[i] + dy * p.Wi + dx) * p.ldx + xoff) * ES : zero;
-      glds16(xs, xdst + i * 4096);
+      xrow[i] = ok ? p.x + ((int64_t)(pix0[i] + dy * p.Wi + dx) * p.ldx + chunk * EPC) * ES : nullptr;
+    }
+  };
+  tap_setup();
+  auto stage = [&](int /*kt*/, int buf) {
+    char *wdst = lds + buf * STAGE_BYTES + wave * 1024;
+    char *xdst = wdst + TILE_BYTES;
+    const int cib = st_c * BKE * ES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(wtap_row[i] ? wtap_row[i] + cib : zero, wdst + i * 4096);
+      glds16(xrow[i] ? xrow[i] + cib : zero, xdst + i * 4096);
+    }
+    if (++st_c == p.cpt) {
+      st_c = 0;
+      if (++st_t < p.ntaps) tap_setup();
     }
   };
 

@@ -44,7 +44,6 @@ struct Igemm256Params {
   int tgeo[4][8];            // per class: kw, kh, dy0, dys, dx0, dxs -- the taps form a kh x kw grid, tap t = ky*kw + kx
                              // sits at (dy0 + dys*ky, dx0 + dxs*kx)
   int stage_out;             // bf16 output tile goes through LDS and leaves as whole 512-B pixel rows
-  int stagger;               // > 0: the first workgroup of every CU starts (blockIdx % 8) * stagger sleep units late
 };
 
 // LDS-staged output (bf16, no split-K): measured with the stamp build, the direct epilogue -- 32 stores per lane, each
@@ -121,11 +120,6 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
     __builtin_amdgcn_sched_barrier(0);                                                  \
   }
   CFD_TSTAMP(0)
-  // De-phasing: all CUs start together and run tiles of equal length, so their output bursts (128 KiB per CU) hit
-  // HBM at the same moment and every CU then waits ~11 us for write bandwidth.  Starting the eight XCDs a fraction
-  // of that apart, once, keeps their bursts apart for the rest of the launch.
-  if (P.stagger > 0 && blockIdx.x < 256)
-    for (int i = (int)(blockIdx.x & 7) * P.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(32);
 
   // ---- XCD-aware block remap (bijective)
   int bid = blockIdx.x;
@@ -1084,10 +1078,6 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   P.stage_out = ntile == 256 && p.out_bf16 && p.split_k == 1 && p.ldy % 8 == 0 && ((uintptr_t)p.y & 15) == 0 &&
                 p.act != CFD_ACT_SIGMOID && tuning(CFD_TUNE_STAGED_OUT) != 0;
   const size_t shmem = P.stage_out ? (size_t)OUT_LDS : (size_t)2 * ST_BYTES;
-  {
-    const int sg = tuning(CFD_TUNE_STAGED_OUT);   // experiment: values >= 10 = stagger units (s_sleep 32 ~ 2048 cycles)
-    P.stagger = (sg >= 10 && p.nblocks > 256) ? sg - 10 : 0;
-  }
   const int pdt = tuning(CFD_TUNE_IGEMM256_PD);
   // persistent form (igemm256p_kernel): bf16, 256-wide n tiles, more tiles than CUs, every K range even
   // (CFD_TUNE_IGEMM256_PD: 36 forces it where legal, 26 forbids it)

@@ -69,8 +69,8 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
   const int oy = kh + p.oy_base, ox = kw + p.ox_base;
 
   const int ktiles = (p.M + 63) >> 6;
-  const int kbeg = (int)((int64_t)ktiles * sm / p.split_m);
-  const int kend = (int)((int64_t)ktiles * (sm + 1) / p.split_m);
+  const int kbeg = k_slice(ktiles, sm, p.split_m);       // 32-bit: ktiles * split_m < 2^31 (host)
+  const int kend = k_slice(ktiles, sm + 1, p.split_m);
   const int nkt = kend - kbeg;
 
   const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void *)p.plain, 0, (int)p.pbytes, 0x00020000);
@@ -321,6 +321,7 @@ int wgrad256_launch(Wgrad256Params &p, const void *x, const void *dy, float *dw,
   p.dw = dw;
   const int ktiles = (p.M + 63) / 64;
   p.split_m = split_m < ktiles ? split_m : ktiles;
+  CFD_REQUIRE((int64_t)ktiles * p.split_m < (1LL << 31), "reduction too long for 32-bit slice arithmetic");
   p.nblocks = p.cotiles * p.citiles * p.ntaps * p.split_m;
   p.dw_elems = (int64_t)p.Cout * p.ntaps * p.Cin;
   CFD_REQUIRE(p.dw_elems < (1LL << 31), "weight tensor too large for 32-bit element offsets");
