@@ -633,7 +633,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
                                                               float *__restrict__ dw, float *__restrict__ db, int B,
                                                               int Hi, int Wi, int Ho, int Wo, int Cout, int pix_per_block) {
   constexpr int NW = KS * KS * CIN;
-  __shared__ float patch[8][NW];
+  constexpr int PIXB = 32;   // pixels per staged step: 32 independent dpre loads per thread in flight per barrier pair
+  __shared__ float patch[PIXB][NW];
   __shared__ float outb[256 * (NW + 1)];   // [co][NW] padded by one against bank conflicts
   const int64_t npix = (int64_t)B * Ho * Wo;
   const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
@@ -643,10 +644,10 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
   float accb = 0.f;
 #pragma unroll
   for (int k = 0; k < NW; ++k) acc[k] = 0.f;
-  for (int64_t pb = p0; pb < p1; pb += 8) {
+  for (int64_t pb = p0; pb < p1; pb += PIXB) {
     __syncthreads();
-    if (threadIdx.x < 8 * NW) {
-      const int pi = threadIdx.x / NW, k = threadIdx.x % NW;
+    for (int e = threadIdx.x; e < PIXB * NW; e += 256) {
+      const int pi = e / NW, k = e % NW;
       const int64_t pix = pb + pi;
       float v = 0.f;
       if (pix < p1) {
@@ -662,15 +663,18 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
     }
     __syncthreads();
     if (co < Cout) {
+      float gv[PIXB];
 #pragma unroll
-      for (int pi = 0; pi < 8; ++pi) {
+      for (int pi = 0; pi < PIXB; ++pi) {   // all loads first (clamped row, masked value): one latency per step
         const int64_t pix = pb + pi;
-        if (pix < p1) {
-          const float g = to_f32(dpre[pix * ldd + co]);
-          accb += g;
+        const float g = to_f32(dpre[(pix < p1 ? pix : p1 - 1) * ldd + co]);
+        gv[pi] = pix < p1 ? g : 0.f;
+      }
 #pragma unroll
-          for (int k = 0; k < NW; ++k) acc[k] = fmaf(g, patch[pi][k], acc[k]);
-        }
+      for (int pi = 0; pi < PIXB; ++pi) {
+        accb += gv[pi];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) acc[k] = fmaf(gv[pi], patch[pi][k], acc[k]);
       }
     }
   }
@@ -939,11 +943,11 @@ extern "C" int cfd_conv_first_wgrad(const float *x, const float *x2, int cin1, i
   hipStream_t st = (hipStream_t)stream;
   const int Ho = Hi / stride, Wo = Wi / stride;
   const int64_t npix = (int64_t)B * Ho * Wo;
-  // ~2048 blocks: eight resident blocks per CU hide the dependent patch / dpre loads of the 8-pixel steps; each block
-  // ends with one contiguous 4-32 KB atomic burst, so the extra blocks cost a few tens of MB of atomics at most
-  int64_t ppb = (npix + 2047) / 2048;
+  // ~1024 blocks of 32-pixel steps (32 dpre loads in flight per thread and barrier pair); each block ends with one
+  // contiguous 4-32 KB atomic burst
+  int64_t ppb = (npix + 1023) / 1024;
   if (ppb < 64) ppb = 64;
-  ppb = (ppb + 7) / 8 * 8;
+  ppb = (ppb + 31) / 32 * 32;
   const int blocks = (int)((npix + ppb - 1) / ppb);
   const int cin = cin1 + cin2;
 #define CFW(T, KS, S, CIN)                                                                                         \

@@ -30,8 +30,8 @@ os.makedirs(dst, exist_ok=True)
 def short(name):
     name = name.replace("void ", "")
     for k in ("igemm256_kernel", "igemm128n_kernel", "igemm_kernel", "wgrad256_kernel", "wgrad_slab_reduce_kernel",
-              "wgrad_kernel", "bn_apply_kernel", "bn_act_bwd_split_kernel", "bn_act_bwd_kernel", "bn_act_kernel",
-              "conv_first_wgrad_kernel", "conv_first_kernel", "adam_kernel", "splitk_epilogue_kernel", "tapgemm",
+              "conv_first_wgrad_kernel", "wgrad_kernel", "bn_apply_kernel", "bn_act_bwd_split_kernel", "bn_act_bwd_kernel", "bn_act_kernel",
+              "conv_first_kernel", "adam_kernel", "splitk_epilogue_kernel", "tapgemm",
               "tap_dw_kernel", "tap_dx_kernel", "transpose_weight_kernel", "maxpool2", "nearest_kernel"):
         if k in name:
             dt = "<bf16>" if ("DF16b" in name or "bf16" in name or "_Accum" in name) else ("<f32>" if ("If" in name or "float" in name) else "")
