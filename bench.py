@@ -246,7 +246,8 @@ def main():
         sm = kt.summary()
         achieved = sm["total_flops"] / (sm["total_ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[wl["dtype"]]
-        traffic, busy = pmc_traffic(args.workload)
+        # the committed PMC passes were taken at the workload's default batch; they say nothing about another one
+        traffic, busy = pmc_traffic(args.workload) if B == wl["batch"] else (None, None)
         roof = dict(bound="mfma", kernel="igemm256_kernel+igemm_kernel" + ("+wgrad_kernel" if train else ""),
                     achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
                     frac=round(achieved / peak, 4), traffic=traffic, mfma_busy_frac_pmc=busy,
