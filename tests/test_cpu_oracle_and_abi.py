@@ -127,3 +127,37 @@ def test_oracle_metrics_pinned_to_sklearn():
     assert emax == e.max() and col.shape == (40,) and abs(emean - e.mean()) < 1e-6
     ref = np.mean([cosine_similarity([y[i]], [Y[i]])[0][0] for i in range(8) if i != 2])
     assert abs(cos - ref) < 1e-6
+
+
+def test_dataset_cache_is_exact_and_keyed_by_content(tmp_path, monkeypatch):
+    """the binary cache returns the parsed doubles bit for bit, skips the CSV parser on a
+    hit, and a changed CSV misses by itself (key = hash of the file's bytes)."""
+    import pandas as pd
+    from cfd_amd import data as D
+    h, w = 8, 16
+    rng = np.random.default_rng(5)
+    folder, cache = tmp_path / "processed", tmp_path / "cache"
+    folder.mkdir()
+    for i in range(3):
+        pd.DataFrame({"y_center": rng.random(h * w), "z_center": rng.random(h * w), "p_center": rng.random(h * w),
+                      "Umean_center": rng.random(h * w) * 3, "p_convert": rng.standard_normal(h * w) * 1e3}
+                     ).to_csv(folder / f"case{i}.csv", index=False)
+    p0, u0 = D.read_cases(str(folder), h, w)                      # no cache
+    p1, u1 = D.read_cases(str(folder), h, w, str(cache))          # fills it
+    assert len(list(cache.iterdir())) == 3
+    real = pd.read_csv
+    monkeypatch.setattr(pd, "read_csv", lambda *a, **k: (_ for _ in ()).throw(AssertionError("parsed on a hit")))
+    p2, u2 = D.read_cases(str(folder), h, w, str(cache))          # hits only
+    for a, b, c in zip(p0 + u0, p1 + u1, p2 + u2):
+        assert a.dtype == np.float64 and np.array_equal(a, b) and np.array_equal(a, c)
+    monkeypatch.setattr(pd, "read_csv", real)
+    first = sorted(os.listdir(folder))[0]
+    df = pd.read_csv(folder / first)
+    df.loc[0, "p_convert"] += 1.0
+    df.to_csv(folder / first, index=False)
+    p3, _ = D.read_cases(str(folder), h, w, str(cache))
+    assert len(list(cache.iterdir())) == 4                        # new key; the stale entry is simply unused
+    k = os.listdir(folder).index(first)
+    assert p3[k][0, 0] == p0[k][0, 0] + 1.0
+    with pytest.raises(ValueError):
+        D.load_data(str(folder), h, w, cache_dir=str(folder / "inside"))
