@@ -59,7 +59,7 @@ def build_nets(names, tdt):
     out = {}
     for n in names:
         if n in ("U", "P"):
-            out[n] = nets.Generator(n, dtype=tdt, seed=hash(n) % 97)
+            out[n] = nets.Generator(n, dtype=tdt, seed={"U": 11, "P": 13}[n])   # fixed: str hashes differ per process
         else:
             out[n] = nets.CnnRegressor(dtype=tdt, seed=5)
     return out
@@ -228,8 +228,9 @@ def main():
         dt = float(t.item())
 
     # ---- roofline of the dominant kernel (igemm): HIP events around every launch, same workload
+    # (a training step holds collectives, so every rank runs this pass when training; rank 0 reports it)
     roof = None
-    if rank == 0:
+    if rank == 0 or (train and world > 1):
         # The brackets must see kernel time only: if the GPU ran dry, the host time between an event record and the
         # launch behind it would count.  A calibrated on-stream delay ahead of every step (outside every bracket)
         # lets the host run a few milliseconds ahead of the GPU for the whole step.
@@ -242,7 +243,7 @@ def main():
         with ops.KernelTimer() as kt:
             for s in range(min(args.steps, 5)):
                 torch.cuda._sleep(head_start)
-                run_step(models, x, 1000 + s, 0)
+                run_step(models, x, 1000 + s, rank * B)
         sm = kt.summary()
         achieved = sm["total_flops"] / (sm["total_ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[wl["dtype"]]

@@ -1,0 +1,134 @@
+"""CPU-only checks of the host side that mirrors the reference's scripts: flags, file conventions, the
+preprocess steps around the resample, the sample helpers of utils.py.  No kernel is launched here."""
+import io
+import os
+import sys
+import zipfile
+
+import numpy as np
+import pandas as pd
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_str2bool_matches_reference_table():
+    """/root/reference/utils.py:23-29: bools pass through, 'true'/'false' in any case, anything else -> None
+    (the reference's `in ('true')` is a substring test on a plain string; whole words are what its callers pass)"""
+    from cfd_amd.cli import str2bool
+    assert str2bool(True) is True and str2bool(False) is False
+    for s in ("true", "True", "TRUE"):
+        assert str2bool(s) is True
+    for s in ("false", "False", "FALSE"):
+        assert str2bool(s) is False
+    assert str2bool("maybe") is None
+
+
+@pytest.mark.parametrize("field,default_dir", [("U", "U/training_U/"), ("P", "P/training_P/"),
+                                               ("DeltaP", "DeltaP/training_DeltaP/")])
+def test_train_flags_and_defaults(field, default_dir):
+    """the five flags of U/train.py:28-34 with the reference's defaults, short and long spellings"""
+    from cfd_amd.cli import train_parser
+    a = train_parser(field).parse_args([])
+    assert (a.checkpoint, a.epocheval, a.numepoch, a.trainpath, a.directory) == \
+        (False, 1, 10000, "30_case_duyanh/processed/", default_dir)
+    a = train_parser(field).parse_args(["-c", "True", "-e", "5", "-n", "7", "-t", "in/", "-d", "out/"])
+    assert (a.checkpoint, a.epocheval, a.numepoch, a.trainpath, a.directory) == (True, 5, 7, "in/", "out/")
+    b = train_parser(field).parse_args(["--checkpoint", "false", "--epocheval", "5", "--numepoch", "7",
+                                        "--trainpath", "in/", "--directory", "out/"])
+    assert b.checkpoint is False and (b.epocheval, b.numepoch) == (5, 7)
+
+
+def test_split_is_the_references_90_10():
+    """train_test_split(range(n), test_size=0.1, random_state=42) (U/train.py:53): BASELINE configs[0] = 100 cases"""
+    from cfd_amd.cli import _split
+    tr, va = _split(100)
+    assert len(tr) == 90 and len(va) == 10 and sorted(tr + va) == list(range(100))
+    tr2, va2 = _split(100)
+    assert tr == tr2 and va == va2                      # deterministic
+    assert va[:3] == [83, 53, 70]                       # sklearn's permutation for seed 42 (pinned here)
+
+
+def test_resume_step_rounds_down_to_an_epoch(tmp_path):
+    """steps.txt holds the global step; training resumes at the start of that epoch (U/train.py:93-101)"""
+    from cfd_amd.cli import _resume_step
+    d = str(tmp_path) + "/"
+    assert _resume_step(d, 90, chkpt=True) == 0         # no file yet
+    open(d + "steps.txt", "w").write("275\n")
+    assert _resume_step(d, 90, chkpt=True) == 270
+    assert _resume_step(d, 90, chkpt=False) == 0
+
+
+def test_generate_samples_shapes_and_labels():
+    """utils.py:33-62: real -> [[A, B], ones(n, patch, 8*patch, 1)], fake -> (G(A), zeros(...)), float32 fields"""
+    import utils
+
+    class G:                                            # stands in for the model object: predict([x]) -> array
+        def predict(self, x):
+            assert isinstance(x, list) and len(x) == 1
+            return np.full(x[0].shape, 0.25, dtype=np.float64)
+
+    xs = [np.full((64, 512, 1), i, dtype=np.float64) for i in range(5)]
+    ys = [np.full((64, 512, 1), -i, dtype=np.float64) for i in range(5)]
+    (a, b), y = utils.generate_real_samples(xs, ys, [3, 1], 4)
+    assert a.dtype == np.float32 and b.dtype == np.float32 and a.shape == (2, 64, 512, 1)
+    assert a[0, 0, 0, 0] == 3 and b[1, 0, 0, 0] == -1
+    assert y.shape == (2, 4, 32, 1) and (y == 1).all()
+    f, y0 = utils.generate_fake_samples(G(), a, 4)
+    assert f.dtype == np.float32 and f.shape == a.shape and (f == 0.25).all()
+    assert y0.shape == (2, 4, 32, 1) and (y0 == 0).all()
+
+
+def _case_csv(n=50, seed=0):
+    r = np.random.default_rng(seed)
+    df = pd.DataFrame({"x": np.zeros(n), "y": r.uniform(-2e-3, 2e-3, n), "z": r.uniform(0, 5e-2, n),
+                       "p": r.normal(size=n), "U_x": r.normal(size=n), "U_y": r.normal(size=n),
+                       "U_z": r.normal(size=n)})
+    return df
+
+
+def test_preprocess_steps_around_the_resample(tmp_path):
+    """pixels_coords_testing.py:77-145 of the reference: nested case archives -> latest time directory's midBox.csv
+    -> Umean + column order -> duplicate rows dropped.  (The resample itself is the GPU tests' business.)"""
+    import pixels_coords_testing as pct
+    inner_dir = "caseA/postProcessing/boxUniform"
+    old, new = _case_csv(seed=1), _case_csv(seed=2)
+    new = pd.concat([new, new.iloc[:7]], ignore_index=True)             # 7 duplicate rows
+    inner = io.BytesIO()
+    with zipfile.ZipFile(inner, "w") as z:
+        z.writestr(f"{inner_dir}/100/midBox.csv", old.to_csv(index=False))
+        z.writestr(f"{inner_dir}/2500.5/midBox.csv", new.to_csv(index=False))
+        z.writestr(f"{inner_dir}/notatime/midBox.csv", "x\n1\n")
+    inner_empty = io.BytesIO()
+    with zipfile.ZipFile(inner_empty, "w") as z:
+        z.writestr("caseB/readme.txt", "no postProcessing here")
+    outer = tmp_path / "cases.zip"
+    with zipfile.ZipFile(outer, "w") as z:
+        z.writestr("caseA.zip", inner.getvalue())
+        z.writestr("caseB.zip", inner_empty.getvalue())
+    out = tmp_path / "out"
+    out.mkdir()
+    pct.process_zip_folder(outer, out)
+    assert sorted(p.name for p in out.iterdir()) == ["caseA_midBox.csv"]      # caseB skipped, unzipped/ removed
+    got = pd.read_csv(out / "caseA_midBox.csv")
+    assert len(got) == len(new) and np.array_equal(got["p"].to_numpy(), pd.read_csv(io.StringIO(new.to_csv(index=False)))["p"].to_numpy())
+
+    pct.calculate_umean_and_restructure(out / "caseA_midBox.csv", tmp_path / "r.csv")
+    r = pd.read_csv(tmp_path / "r.csv")
+    assert list(r.columns) == ["x", "y", "z", "p", "Umean"]
+    want = np.sqrt(got["U_x"] ** 2 + got["U_y"] ** 2 + got["U_z"] ** 2).to_numpy()
+    assert np.allclose(r["Umean"].to_numpy(), want, rtol=1e-15, atol=0)
+    assert len(r.drop_duplicates()) == len(new) - 7
+
+    bad = tmp_path / "bad.zip"
+    bad.write_bytes(b"not a zip")
+    pct.extract_zip(bad, tmp_path / "nowhere")                          # reported, not raised (:73-74)
+
+
+def test_read_points_rejects_a_wrong_table(tmp_path):
+    import pixels_coords_testing as pct
+    p = tmp_path / "c.csv"
+    pd.DataFrame({"x": [0.0], "y": [0.0], "z": [0.0]}).to_csv(p, index=False)
+    with pytest.raises(ValueError, match="expected 5 columns"):
+        pct._read_points(p)
