@@ -161,3 +161,38 @@ def test_dataset_cache_is_exact_and_keyed_by_content(tmp_path, monkeypatch):
     assert p3[k][0, 0] == p0[k][0, 0] + 1.0
     with pytest.raises(ValueError):
         D.load_data(str(folder), h, w, cache_dir=str(folder / "inside"))
+
+
+def test_oracle_losses_and_adam_match_keras_published_examples():
+    """Known answers printed in the Keras API documentation (the third-party library the reference's arithmetic
+    lives in; not installed here) -- the only published numbers for this path, so the oracle's loss and optimizer
+    restatements are pinned to them:
+      keras.losses.BinaryCrossentropy  y_true [[0,1],[0,0]], y_pred [[.6,.4],[.4,.6]] -> 0.815
+      keras.losses.Huber               same operands                                  -> 0.155
+      keras.losses.MeanAbsoluteError   y_true [[0,1],[0,0]], y_pred [[1,1],[1,0]]     -> 0.5
+      keras.losses.MeanSquaredError    same operands                                  -> 0.5
+      keras.layers.LeakyReLU(negative_slope=0.5) on [-3,-1,0,2]                       -> [-1.5,-0.5,0,2]
+      keras.optimizers.Adam(learning_rate=0.1), var 10.0, loss var**2/2, one step      -> 9.9"""
+    from oracle import keras_semantics as KS
+    yt = np.array([[0., 1.], [0., 0.]], np.float32)
+    yp = np.array([[0.6, 0.4], [0.4, 0.6]], np.float32)
+    logits = torch.log(torch.tensor(yp) / (1 - torch.tensor(yp)))
+    for from_logits in (True, False):
+        old, KS.BCE_FROM_LOGITS = KS.BCE_FROM_LOGITS, from_logits
+        try:
+            assert abs(float(O.bce_from_logits(logits, yt)) - 0.815) < 5e-4
+        finally:
+            KS.BCE_FROM_LOGITS = old
+    assert abs(float(O.huber(yt, yp)) - 0.155) < 1e-6
+    yq = np.array([[1., 1.], [1., 0.]], np.float32)
+    assert float(O.mae(yt, yq)) == 0.5 and float(O.mse(yt, yq)) == 0.5
+    assert KS.LEAKY_SLOPE == 0.2
+    x = torch.tensor([-3., -1., 0., 2.])
+    assert torch.equal(torch.where(x > 0, x, x * 0.5), torch.tensor([-1.5, -0.5, 0., 2.]))
+    assert torch.equal(O.leaky(x), torch.where(x > 0, x, x * KS.LEAKY_SLOPE))
+    # Adam: "the first step is -learning_rate * sign(grad)" (Keras/TF docs), whatever beta_1
+    for b1 in (0.9, 0.5):
+        p = {"w": torch.tensor([10.0])}
+        opt = O.KerasAdam(0.1, b1)
+        opt.step(p, {"w": p["w"].clone()})          # d(w^2/2)/dw = w
+        assert abs(float(p["w"]) - 9.9) < 1e-6
