@@ -15,8 +15,10 @@ The reference's entry scripts touch their Keras models through a handful of name
 Same names, same argument meaning, numpy NHWC fp32 in / numpy out, Python exceptions on error.
 Everything below the method calls runs on the HIP kernels (cfd_amd.nets / cfd_amd.trainer).
 
-Environment switches (opt-in, the defaults reproduce the reference):
-  CFD_AMD_DTYPE = bf16 | fp32   compute dtype of the MFMA kernels (default bf16)
+Environment switches:
+  CFD_AMD_DTYPE = bf16 | fp32   arithmetic type of the MFMA kernels.  Default bf16 (north_star's target arithmetic: fp32
+                                accumulation, outputs within 2e-2 of the fp32 oracle); fp32 is the reference's own
+                                arithmetic (Keras float32), within 1e-4 of the oracle, ~2.5x slower.
 """
 from __future__ import annotations
 
