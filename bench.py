@@ -271,6 +271,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
+        barrier(world)                      # rank 0 ran the roofline pass alone: leave together
         dist.destroy_process_group()
 
 
