@@ -400,6 +400,21 @@ def resample_nearest(cases, height: int = 64, width: int = 512, device="cuda", r
     return out if return_device else out.cpu().numpy()
 
 
+def csv_format_rows(rows: np.ndarray) -> bytes:
+    """(n_rows, n_cols) fp64 HOST table -> the body of the CSV pandas' `to_csv(index=False)` writes for it, byte for byte
+    (pixels_coords_testing.py:223-226), formatted by the library's host-side writer (cfd_csv_format_rows)."""
+    lib = _lib.load()
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    if rows.ndim != 2 or rows.shape[1] < 1:
+        raise ValueError("rows must be (n_rows, n_cols) with n_cols >= 1")
+    cap = rows.shape[0] * rows.shape[1] * 26
+    buf = C.create_string_buffer(max(cap, 1))
+    n = lib.cfd_csv_format_rows(rows.ctypes.data, rows.shape[0], rows.shape[1], C.addressof(buf), cap)
+    if n < 0:
+        check(int(n), "cfd_csv_format_rows")
+    return buf.raw[:n]
+
+
 def dataset_grids(p: np.ndarray, cell: float, device="cuda", return_device: bool = False):
     """p: (ncase, H, W) fp64 `p_convert` grids.  Returns (sdf (ncase,H,W) fp64, delta_p (ncase,) fp64): the model
     input and DeltaP of utils.load_data (utils.py:89-103), computed on the GPU.  Raises ValueError for a case without

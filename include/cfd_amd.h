@@ -270,6 +270,15 @@ int cfd_resample_nearest(const double *pts, const int64_t *case_offsets, int nca
                          const double *z_final, int W, const double *z_samples, int S, double tol1, double tol2,
                          double p_convert, double *out, void *workspace, void *stream);
 
+/* Host-side text form of the resample's result table (no device work, no stream).
+ * Replaces `df_out.to_csv(output_csv, index=False)`, pixels_coords_testing.py:223-226 (pandas' writer: every fp64 as
+ * repr(float) = shortest round-trip decimal in CPython's layout, NaN as the empty field).  SAME BYTES as pandas, without
+ * the header line; ~30x faster, and the preprocess of a folder is otherwise nothing but this call.
+ *   rows   HOST fp64 [n_rows][n_cols], row-major
+ *   out    HOST char buffer of `cap` >= n_rows * n_cols * 26 bytes
+ * Returns the number of bytes written (>= 0), or a negative cfd_status. */
+int64_t cfd_csv_format_rows(const double *rows, int64_t n_rows, int n_cols, char *out, int64_t cap);
+
 /* ------------------------------------------------------------------------------------
  * Dataset build: what utils.load_data computes per case after parsing the CSV (utils.py:89-103).
  *   p            fp64 [ncase][H][W]: the `p_convert` column reshaped (device)

@@ -132,3 +132,46 @@ def test_read_points_rejects_a_wrong_table(tmp_path):
     pd.DataFrame({"x": [0.0], "y": [0.0], "z": [0.0]}).to_csv(p, index=False)
     with pytest.raises(ValueError, match="expected 5 columns"):
         pct._read_points(p)
+
+
+def _pandas_body(a, cols):
+    s = io.StringIO()
+    pd.DataFrame(a, columns=cols).to_csv(s, index=False)
+    txt = s.getvalue()
+    return txt[txt.index("\n") + 1:].encode()
+
+
+def test_csv_writer_is_byte_identical_to_pandas(tmp_path):
+    """cfd_csv_format_rows (host-side writer of the resample's result table) against the real pandas `to_csv` the
+    reference calls (pixels_coords_testing.py:226): same bytes for every magnitude, the layout switches of repr(float)
+    (1e-4 / 1e-5, 1e15 / 1e16), integers, signed zeros, subnormals, extremes, inf and NaN."""
+    from cfd_amd import ops
+    r = np.random.default_rng(7)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 1e-4, 9.999e-5, 1e-5, 1.5e-7, 123456789012345.0, 1e15, 9999999999999998.0,
+                        1e16, 1.2345e16, 1e22, 1e23, 1.7976931348623157e308, 2.2250738585072014e-308, 5e-324, 1e-310,
+                        0.1, 0.2 + 0.1, 1 / 3, 2 / 3, 100.0, 1072.033, 0.001953125, -0.002 + 0.5 * 4e-3 / 64,
+                        np.inf, -np.inf, np.nan, 1e100, 1.5e-100, 123.456, 4503599627370496.0, 9007199254740993.0])
+    special = np.concatenate([special, np.full(4 - len(special) % 4, 7.25)]) if len(special) % 4 else special
+    mags = 10.0 ** r.integers(-320, 308, size=4000).astype(np.float64)
+    with np.errstate(over="ignore", under="ignore"):
+        rnd = np.concatenate([r.normal(size=4000) * mags, r.normal(size=2000), r.integers(-10**6, 10**6, 2000).astype(np.float64),
+                              np.frombuffer(r.bytes(8 * 4000), dtype=np.float64)])
+    a = np.concatenate([special, rnd[: len(rnd) // 4 * 4]]).reshape(-1, 4)
+    cols = ["a", "b", "c", "d"]
+    got, want = ops.csv_format_rows(a), _pandas_body(a, cols)
+    if got != want:
+        g, w = got.split(b"\n"), want.split(b"\n")
+        bad = [(i, x, y) for i, (x, y) in enumerate(zip(g, w)) if x != y][:5]
+        raise AssertionError(f"{len(g)} vs {len(w)} lines; first differences: {bad}")
+    # the preprocess writer end to end: a realistic result table, header included, read back to the same doubles
+    import pixels_coords_testing as pct
+    tab = np.column_stack([np.repeat(-0.002 + (np.arange(8) + 0.5) * 4e-3 / 8, 16), np.tile((np.arange(16) + 0.5) * 50e-3 / 16, 8),
+                           r.uniform(0, 3, 128), r.uniform(0, 2, 128), r.uniform(0, 3000, 128)])
+    tab[::5, 2:] = 0.0
+    pct._write_table(tab, tmp_path / "t.csv")
+    ref = io.StringIO()
+    pd.DataFrame(tab, columns=pct.OUT_COLUMNS).to_csv(ref, index=False)
+    assert (tmp_path / "t.csv").read_bytes() == ref.getvalue().encode()
+    assert ops.csv_format_rows(np.zeros((0, 5))) == b""
+    with pytest.raises(ValueError):
+        ops.csv_format_rows(np.zeros(5))
