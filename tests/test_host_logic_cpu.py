@@ -175,3 +175,25 @@ def test_csv_writer_is_byte_identical_to_pandas(tmp_path):
     assert ops.csv_format_rows(np.zeros((0, 5))) == b""
     with pytest.raises(ValueError):
         ops.csv_format_rows(np.zeros(5))
+
+
+def test_read_cases_threaded_equals_serial_in_listing_order(tmp_path, monkeypatch):
+    """utils.py:70-87 reads the folder in os.listdir order; the threaded ingest must return the same grids in that order"""
+    from cfd_amd import data as D
+    r = np.random.default_rng(3)
+    folder = tmp_path / "processed"
+    folder.mkdir()
+    (folder / "a_directory").mkdir()                   # not a file: skipped, as the reference's isfile test does
+    for i in range(9):
+        a = r.normal(size=(8 * 16, 5))
+        pd.DataFrame(a, columns=["y_center", "z_center", "p_center", "Umean_center", "p_convert"]).to_csv(
+            folder / f"case_{(i * 7) % 9}.csv", index=False)
+    monkeypatch.setattr(D, "INGEST_THREADS", 1)
+    ps1, us1 = D.read_cases(str(folder), 8, 16)
+    monkeypatch.setattr(D, "INGEST_THREADS", 4)
+    ps4, us4 = D.read_cases(str(folder), 8, 16)
+    assert len(ps1) == len(ps4) == 9
+    assert all(np.array_equal(a, b) for a, b in zip(ps1, ps4)) and all(np.array_equal(a, b) for a, b in zip(us1, us4))
+    names = [n for n in os.listdir(folder) if os.path.isfile(folder / n)]
+    first = pd.read_csv(folder / names[0])["p_convert"].to_numpy().reshape(8, 16)
+    assert np.array_equal(ps4[0], first)
