@@ -7,8 +7,10 @@ nearest-neighbour resample of every CSV onto the height x width pixel grid.  The
 cases of the folder in one launch.  Plotting (:233-340) is out of scope.
 """
 import argparse
+import os
 import shutil
 import zipfile
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import numpy as np
@@ -16,6 +18,7 @@ import pandas as pd
 
 height, width = 64, 512      # module globals, as in the reference (:360-361)
 OUT_COLUMNS = ["y_center", "z_center", "p_center", "Umean_center", "p_convert"]
+IO_THREADS = min(16, os.cpu_count() or 1)
 
 
 def _read_points(csv_path) -> np.ndarray:
@@ -47,9 +50,10 @@ def process_all_csvs_with_pixel_coordinates(output_folder, cases_per_launch: int
     files = sorted(Path(output_folder).glob("*.csv"))
     for s in range(0, len(files), cases_per_launch):
         chunk = files[s:s + cases_per_launch]
-        out = ops.resample_nearest([_read_points(f) for f in chunk], height, width)
-        for f, rows in zip(chunk, out):
-            _write_table(rows, f)
+        with ThreadPoolExecutor(max_workers=IO_THREADS) as ex:       # parser and formatter both release the GIL
+            out = ops.resample_nearest(list(ex.map(_read_points, chunk)), height, width)
+            list(ex.map(_write_table, out, chunk))
+        for f in chunk:
             print(f"Nearest interpolation: {f}")
 
 
