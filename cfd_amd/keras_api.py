@@ -65,6 +65,33 @@ class _GraphedForward:
         return self.y
 
 
+PREDICT_CHUNK = 128    # cases per forward pass of a large predict (CFD_AMD_PREDICT_CHUNK): the bench's batch
+
+
+def _predict_chunk() -> int:
+    return max(1, int(os.environ.get("CFD_AMD_PREDICT_CHUNK", PREDICT_CHUNK)))
+
+
+def _forward_chunked(forward, xd: torch.Tensor, with_sample0: bool, **kw) -> torch.Tensor:
+    """`forward` over xd in chunks of PREDICT_CHUNK cases, results gathered in one device tensor.  Keras' predict
+    batches the same way (batch_size=32).  Every case is independent of its batch here (per-sample BatchNorm statistics,
+    dropout keyed by the sample index `sample0 + i`), so the chunking changes no result; it bounds the activation
+    workspace (U at fp32: ~45 MB a case) and keeps every kernel's element count far below 2^31 however many cases
+    (configs[2]: 1250 per GPU) one call hands over."""
+    B, C = xd.shape[0], _predict_chunk()
+    if B <= C:
+        return forward(xd, **kw)
+    out = None
+    for lo in range(0, B, C):
+        if with_sample0:
+            kw["sample0"] = lo
+        y = forward(xd[lo:lo + C], **kw)           # a slice along the batch axis is contiguous
+        if out is None:
+            out = torch.empty((B,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+        out[lo:lo + C].copy_(y)                     # y lives in the net's reused buffers
+    return out
+
+
 def _use_graphs() -> bool:
     return os.environ.get("CFD_AMD_GRAPHS", "1") != "0"
 
@@ -163,12 +190,12 @@ class GeneratorModel(Model):
                 # bit 59 of the seed -> bit 63 of every layer's drop_seed (seed * 16 + layer): epoch-keyed
                 g = self._graphs[B] = _GraphedForward(self.net, xd, seed=(1 << 59) | (self._next_seed() & ((1 << 59) - 1)))
             return g(xd).cpu().numpy()
-        return self.net.forward(xd, seed=self._next_seed()).cpu().numpy()
+        return _forward_chunked(self.net.forward, xd, True, seed=self._next_seed()).cpu().numpy()
 
     def predict_on_device(self, x) -> torch.Tensor:
         """predict without the copy back to the host (not in Keras): the evaluation drivers feed the result to
         ops.eval_metrics and fetch a few numbers per case instead of the fields"""
-        return self.net.forward(_dev(x), seed=self._next_seed())
+        return _forward_chunked(self.net.forward, _dev(x), True, seed=self._next_seed())
 
     __call__ = predict
 
@@ -278,7 +305,7 @@ class CnnModel(Model):
             if g is None:
                 g = self._graphs[B] = _GraphedForward(self.net, xd, training=False)
             return g(xd).cpu().numpy()
-        return self.net.forward(xd, training=False).cpu().numpy()
+        return _forward_chunked(self.net.forward, xd, False, training=False).cpu().numpy()
 
     def train_on_batch(self, x, y):
         return self._tr().train_on_batch(_dev(x), _dev(y).reshape(-1, 1), seed=self._next_seed())

@@ -121,3 +121,36 @@ def test_predict_hip_graph_and_empty_batch(monkeypatch):
         ops.bn_act_bwd(r, v, v, v[0], v[0], r, ops.ACT_RELU, torch.empty_like(r), torch.zeros(64, device="cuda"),
                        torch.zeros(64, device="cuda"), drop_rate=0.5, drop_seed=(1 << 63) | 5)
     ops.dropout_epoch(0, set_=True)
+
+
+def test_predict_in_chunks_equals_one_pass(monkeypatch):
+    """A predict over more cases than CFD_AMD_PREDICT_CHUNK runs chunk by chunk (a ragged last chunk included) and
+    returns what one pass over the whole batch returns: per-sample BatchNorm statistics, dropout keyed by the sample
+    index.  Only the split-K factor (fp32 summation order) may differ with the batch size, as in
+    test_generator_batch_equals_single.  The DeltaP CNN has no dropout at inference; U has three dropout layers."""
+    import torch
+    from cfd_amd import keras_api as K, synthetic
+    monkeypatch.setenv("CFD_AMD_DTYPE", "fp32")
+    monkeypatch.setenv("CFD_AMD_GRAPHS", "0")       # batches <= 8 would replay a graph with an epoch-keyed draw
+    x, _, _ = synthetic.model_batch(range(5))
+    xd = torch.from_numpy(x).cuda()
+    g = K.define_generator_U((64, 512, 1))
+    c = K.define_cnn_model((64, 512, 1))
+    g._seed = 77
+    seed = g._next_seed()
+    whole = g.net.forward(xd, seed=seed).cpu().numpy().copy()
+    whole_c = c.net.forward(xd, training=False).cpu().numpy().copy()
+    monkeypatch.setenv("CFD_AMD_PREDICT_CHUNK", "2")
+    g._seed = 77
+    y = g.predict(x)
+    g._seed = 77
+    yd = g.predict_on_device(x).cpu().numpy()
+    yc = c.predict(x)
+    assert y.shape == whole.shape and yc.shape == (5, 1)
+    assert np.abs(y - whole).max() <= 1e-5 * np.abs(whole).max()
+    assert np.abs(y - yd).max() <= 1e-5 * np.abs(whole).max()    # two runs differ by the commit order of the BN atomics
+    assert np.abs(yc - whole_c).max() <= 1e-5 * max(np.abs(whole_c).max(), 1e-30)
+    # a different chunking of the same call: the same draw again (sample-indexed dropout), chunk 3 + 2
+    monkeypatch.setenv("CFD_AMD_PREDICT_CHUNK", "3")
+    g._seed = 77
+    assert np.abs(g.predict(x) - whole).max() <= 1e-5 * np.abs(whole).max()
