@@ -197,3 +197,30 @@ def test_read_cases_threaded_equals_serial_in_listing_order(tmp_path, monkeypatc
     names = [n for n in os.listdir(folder) if os.path.isfile(folder / n)]
     first = pd.read_csv(folder / names[0])["p_convert"].to_numpy().reshape(8, 16)
     assert np.array_equal(ps4[0], first)
+
+
+def test_forward_chunked_host_logic(monkeypatch):
+    """keras_api._forward_chunked with a stand-in forward on CPU tensors: chunk boundaries, the ragged tail, the
+    sample0 offsets handed to the forward, and that each chunk's result is copied out of the (reused) buffer."""
+    import torch
+    from cfd_amd import keras_api as K
+    calls = []
+    scratch = torch.empty(4, 3)                      # like the nets: every forward returns the same reused buffer
+
+    def forward(x, seed=0, sample0=0):
+        calls.append((x.shape[0], seed, sample0))
+        scratch[:x.shape[0]] = x * 2 + sample0
+        return scratch[:x.shape[0]]
+
+    x = torch.arange(30, dtype=torch.float32).view(10, 3)
+    monkeypatch.setenv("CFD_AMD_PREDICT_CHUNK", "4")
+    y = K._forward_chunked(forward, x, True, seed=9)
+    assert calls == [(4, 9, 0), (4, 9, 4), (2, 9, 8)]
+    off = torch.tensor([0] * 4 + [4] * 4 + [8] * 2, dtype=torch.float32).view(10, 1)
+    assert torch.equal(y, x * 2 + off)
+    calls.clear()
+    y = K._forward_chunked(lambda x, training=False: (calls.append(x.shape[0]), x + 1)[1], x, False, training=False)
+    assert calls == [4, 4, 2] and torch.equal(y, x + 1)
+    calls.clear()
+    monkeypatch.setenv("CFD_AMD_PREDICT_CHUNK", "16")     # one pass: the forward's own buffer is returned as is
+    assert K._forward_chunked(forward, x[:3], True, seed=1) is not None and calls == [(3, 1, 0)]
