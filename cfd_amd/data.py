@@ -22,6 +22,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 CACHE_ENV = "CFD_AMD_DATA_CACHE"
+CACHE_VERSION = "v2"      # v2: values parsed as float() does (round-trip exact); v1 entries (default parser) are never read
 # parser threads of read_cases (CFD_AMD_INGEST_THREADS; the GPU box gives a one-GPU job 16 host threads)
 INGEST_THREADS = int(os.environ.get("CFD_AMD_INGEST_THREADS", "0")) or min(16, os.cpu_count() or 1)
 
@@ -53,13 +54,16 @@ def read_case(path: str, height: int = 64, width: int = 512, cache_dir: Optional
     entry = None
     if cache_dir:
         key = hashlib.blake2b(raw, digest_size=16).hexdigest()
-        entry = os.path.join(cache_dir, f"{key}_{height}x{width}.npy")
+        entry = os.path.join(cache_dir, f"{key}_{height}x{width}_{CACHE_VERSION}.npy")
         if os.path.exists(entry):
             a = np.load(entry, allow_pickle=False)
             if a.shape == (2, height, width) and a.dtype == np.float64:
                 return a[0], a[1]
     import pandas as pd
-    df = pd.read_csv(io.BytesIO(raw))
+    # the reference parses every field with Python's float() (utils.py:81-83: csv.DictReader + float(row[...])), which
+    # is correctly rounded; pandas' DEFAULT parser is not (last-bit differences in ~15 % of values), its
+    # "round_trip" parser is (it calls the same strtod as float()): CPU-tested against a csv.DictReader restatement
+    df = pd.read_csv(io.BytesIO(raw), float_precision="round_trip")
     p = np.asarray(df["p_convert"].to_numpy(), dtype=np.float64).reshape(height, width)
     u = np.asarray(df["Umean_center"].to_numpy(), dtype=np.float64).reshape(height, width)
     if entry:

@@ -195,8 +195,36 @@ def test_read_cases_threaded_equals_serial_in_listing_order(tmp_path, monkeypatc
     assert len(ps1) == len(ps4) == 9
     assert all(np.array_equal(a, b) for a, b in zip(ps1, ps4)) and all(np.array_equal(a, b) for a, b in zip(us1, us4))
     names = [n for n in os.listdir(folder) if os.path.isfile(folder / n)]
-    first = pd.read_csv(folder / names[0])["p_convert"].to_numpy().reshape(8, 16)
+    first = _dictreader_column(folder / names[0], "p_convert").reshape(8, 16)
     assert np.array_equal(ps4[0], first)
+
+
+def _dictreader_column(path, col):
+    """the reference's parse, restated: utils.py:72-83 (csv.DictReader, float(row[col]))"""
+    import csv
+    with open(path, "r") as fh:
+        return np.asarray([float(row[col]) for row in csv.DictReader(fh)], dtype=np.float64)
+
+
+def test_read_case_parses_like_python_float(tmp_path):
+    """A8: utils.py:82-83 parses with float(); pandas' default parser differs from it in the last bit for ~15 % of
+    17-digit values, so the ingest uses the round-trip parser.  200 000 values, bit for bit."""
+    from cfd_amd import data as D
+    r = np.random.default_rng(11)
+    h, w = 200, 500
+    a = np.concatenate([r.normal(size=(h * w // 2, 2)) * 10.0 ** r.integers(-8, 8, size=(h * w // 2, 1)),
+                        r.uniform(0, 3000, size=(h * w - h * w // 2, 2))])
+    path = tmp_path / "case.csv"
+    with open(path, "w") as fh:
+        fh.write("y_center,z_center,p_center,Umean_center,p_convert\n")
+        for u, p in a:
+            fh.write("0.0,0.0,0.0,%s,%s\n" % (repr(float(u)), "%.17g" % p))   # shortest and 17-digit spellings
+    p_got, u_got = D.read_case(str(path), h, w)
+    p_ref, u_ref = _dictreader_column(path, "p_convert"), _dictreader_column(path, "Umean_center")
+    assert np.array_equal(p_got.ravel().view(np.uint64), p_ref.view(np.uint64))
+    assert np.array_equal(u_got.ravel().view(np.uint64), u_ref.view(np.uint64))
+    default = pd.read_csv(path)["p_convert"].to_numpy()
+    assert (default.view(np.uint64) != p_ref.view(np.uint64)).any(), "the default parser no longer differs: test is vacuous"
 
 
 def test_forward_chunked_host_logic(monkeypatch):
