@@ -1,4 +1,5 @@
-"""python DeltaP/test.py [processed_folder] -- per-case evaluation of the saved generator (reference: DeltaP/test.py)."""
+"""python DeltaP/test.py [processed_folder [train_folder]] -- per-case evaluation of the saved model (reference:
+DeltaP/test.py; which cases are scored and the de-normalisation: cfd_amd.cli.EVAL_PLANS[("DeltaP", "test")])."""
 import os
 import sys
 
@@ -6,5 +7,6 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")
 from cfd_amd import cli  # noqa: E402
 
 if __name__ == "__main__":
-    folder = sys.argv[1] if len(sys.argv) > 1 else "./100_case_si/processed/"
-    cli.evaluate("DeltaP", folder, out_dir="./DeltaP/evaluation_test/")
+    folder = sys.argv[1] if len(sys.argv) > 1 else None
+    train_folder = sys.argv[2] if len(sys.argv) > 2 else None
+    cli.evaluate("DeltaP", folder, mode="test", train_folder=train_folder)

@@ -191,35 +191,105 @@ def train(field: str, argv=None, image_shape=(64, 512, 1), models=None):
     return hist
 
 
-def evaluate(field: str, processed_folder: str, model_path: Optional[str] = None, out_dir: Optional[str] = None,
-             model=None, batch: int = 32, image_shape=(64, 512, 1), holdout_last_fraction: float = 0.1):
-    """valid.py / test.py: per-case prediction on the held-out tail of the folder (U/valid.py:44-51 takes the
-    last 10 % in listing order), abs / % error, row-wise cosine similarity, one CSV row per case
-    (U/valid.py:71-117).  Predictions are BATCHED here (per-sample BatchNorm makes a batch of B equal to B
-    single predictions); the reference loops one predict per case (utils.py:52-62)."""
+# What each of the reference's six evaluation scripts scores, and with which de-normalisation (file:line under the
+# reference root).  `select`: "tail" = the last 10 % of the folder in listing order; "all" = every case of the folder;
+# "indices" = the cases of valid_indices.txt saved by the training script.  `scale_from`: where P_max comes from --
+# "folder" = the train_indices.txt cases of the evaluated folder, "train_folder" = those of a second (training) folder.
+# `factor`: the multiple of P_max the prediction is multiplied with, AS WRITTEN in the reference (SURVEY.md "quirks":
+# P trains on y / P_max but evaluates with 2 * P_max; DeltaP/test.py is a copy of P/test.py and inherits its factor).
+EVAL_PLANS = {
+    ("U", "valid"): dict(folder="./100_case_si/processed/", select="tail", scale_from=None, factor=1.0),           # U/valid.py:41-51
+    ("U", "test"): dict(folder="./30_case_duyanh/processed/", select="all", scale_from=None, factor=1.0),          # U/test.py:43,77-86
+    ("P", "valid"): dict(folder="./100_case_si_test/processed/", select="indices", scale_from="folder", factor=2.0),  # P/valid.py:42-66,95
+    ("P", "test"): dict(folder="./30_case_duyanh/processed/", train_folder="./100_case_si/processed/", select="all",
+                        scale_from="train_folder", factor=2.0),                                                    # P/test.py:43,76-90,123-125,168
+    ("DeltaP", "valid"): dict(folder="./130_case/processed/", select="indices", scale_from="folder", factor=1.0),  # DeltaP/valid.py:78-126,157
+    ("DeltaP", "test"): dict(folder="./30_case_duyanh/processed/", train_folder="./100_case_si/processed/", select="all",
+                             scale_from="train_folder", factor=2.0),                                               # DeltaP/test.py:43,76-90,123-125,168
+}
+EVAL_CSV = "error_test_UX_ibm_cylinder.csv"      # the file name every one of the six scripts writes (U/valid.py:69)
+
+
+def eval_selection(field: str, mode: str, n_cases: int, train_idx=None, valid_idx=None):
+    """-> indices (into the evaluated folder's listing order) of the cases `<field>/<mode>.py` scores.  Pure host logic."""
+    plan = EVAL_PLANS[(field, mode)]
+    if plan["select"] == "tail":                                  # U/valid.py:44-51
+        train_size = int(0.9 * n_cases + 1)
+        test_size = n_cases - train_size
+        if test_size <= 0:
+            raise ValueError("not enough cases for a hold-out split")
+        return list(range(n_cases - test_size, n_cases))
+    if plan["select"] == "all":                                   # U/test.py:77-86 (train_size = 0)
+        return list(range(n_cases))
+    if valid_idx is None:
+        raise ValueError(f"{field}/{mode}.py selects its cases with valid_indices.txt: none given")
+    idx = [int(i) for i in np.atleast_1d(valid_idx)]
+    if any(i < 0 or i >= n_cases for i in idx):
+        raise ValueError("valid_indices.txt does not belong to this folder (index out of range)")
+    return idx
+
+
+def eval_scale(field: str, mode: str, train_targets, train_idx=None) -> float:
+    """-> the number a prediction is multiplied with.  `train_targets`: the per-case targets (P grids, or DeltaP values)
+    of the folder `scale_from` names, in listing order; P_max = max over its train_indices.txt cases
+    (P/valid.py:53-66, P/test.py:79-84, DeltaP/valid.py:92-124)."""
+    plan = EVAL_PLANS[(field, mode)]
+    if plan["scale_from"] is None:
+        return 1.0
+    if train_idx is None:
+        raise ValueError(f"{field}/{mode}.py takes P_max from the train_indices.txt cases: none given")
+    idx = [int(i) for i in np.atleast_1d(train_idx)]
+    if not idx or any(i < 0 or i >= len(train_targets) for i in idx):
+        raise ValueError("train_indices.txt does not belong to the training folder (index out of range)")
+    sel = np.asarray([train_targets[i] for i in idx])
+    if field == "DeltaP" and mode == "valid":
+        sel = sel.astype("float32")                               # DeltaP/valid.py:110 casts before :124's max
+    return float(plan["factor"]) * float(sel.max())
+
+
+def evaluate(field: str, processed_folder: Optional[str] = None, model_path: Optional[str] = None,
+             out_dir: Optional[str] = None, model=None, batch: int = 32, image_shape=(64, 512, 1), mode: str = "valid",
+             train_folder: Optional[str] = None, indices_dir: Optional[str] = None):
+    """`<field>/valid.py` (mode "valid") or `<field>/test.py` (mode "test"): which cases are scored and how the
+    prediction is de-normalised follow EVAL_PLANS, one entry per reference script; per-case abs / % error, row-wise
+    cosine similarity, one CSV row per case (U/valid.py:71-117; DeltaP/valid.py:146-173 writes abs / relative error).
+    `indices_dir` holds train_indices.txt / valid_indices.txt (default `<root>/training_<field>/`, where the training
+    script saved them).  Predictions are BATCHED here (per-sample BatchNorm makes a batch of B equal to B single
+    predictions); the reference loops one predict per case (utils.py:52-62)."""
     f = FIELDS[field]
-    model_path = model_path or (f["root"] + "/" + os.path.basename(os.path.normpath(f["default_dir"])) + "/model_ckpt/model_G.keras")
-    out_dir = out_dir or (f["root"] + "/evaluation_valid/")
+    plan = EVAL_PLANS[(field, mode)]
+    train_dir = f["root"] + os.path.basename(os.path.normpath(f["default_dir"])) + "/"
+    processed_folder = processed_folder or plan["folder"]
+    model_path = model_path or (train_dir + "model_ckpt/model_G.keras")
+    out_dir = out_dir or (f["root"] + ("evaluation_valid/" if mode == "valid" else "evaluation_test/"))
+    indices_dir = indices_dir or train_dir
     model = model or K.load_model(model_path, compile=False)
     bnd, sp, su, dps = D.load_data(processed_folder, image_shape[0], image_shape[1])
-    n = len(bnd)
-    train_size = int((1 - holdout_last_fraction) * n + 1)
-    test_size = n - train_size
-    if test_size <= 0:
-        raise ValueError("not enough cases for a hold-out split")
-    x_test = _nhwc(bnd[-test_size:])
-    if field == "U":
-        y_test, scale = np.asarray(su[-test_size:], dtype="float32"), 1.0
-    elif field == "P":
-        p_max = float(np.asarray(sp[:train_size]).max())
-        y_test, scale = np.asarray(sp[-test_size:], dtype="float32"), 2.0 * p_max       # P/valid.py:95 (as written)
+    train_idx = valid_idx = None
+    if plan["select"] == "indices" or plan["scale_from"]:
+        train_idx = np.loadtxt(os.path.join(indices_dir, "train_indices.txt"), dtype=int)
+    if plan["select"] == "indices":
+        valid_idx = np.loadtxt(os.path.join(indices_dir, "valid_indices.txt"), dtype=int)
+    sel = eval_selection(field, mode, len(bnd), train_idx, valid_idx)
+    if plan["scale_from"] == "train_folder":
+        _b, tsp, _su, tdps = D.load_data(train_folder or plan["train_folder"], image_shape[0], image_shape[1])
+        scale = eval_scale(field, mode, tsp if field == "P" else tdps, train_idx)
     else:
-        p_max = float(np.asarray(dps[:train_size]).max())
-        y_test, scale = np.asarray(dps[-test_size:], dtype="float32"), p_max
+        scale = eval_scale(field, mode, sp if field == "P" else dps, train_idx)
+    test_size = len(sel)
+    x_test = _nhwc([bnd[i] for i in sel])
+    if field == "U":
+        y_test = np.asarray([su[i] for i in sel], dtype="float32")
+    elif field == "P":
+        y_test = np.asarray([sp[i] for i in sel], dtype="float32")
+    else:
+        y_test = np.asarray([dps[i] for i in sel], dtype="float32")
     os.makedirs(out_dir, exist_ok=True)
     rows, mean_err = [], 0.0
     if field == "DeltaP":
-        pred = np.concatenate([model.predict(x_test[s:s + batch]) for s in range(0, test_size, batch)], axis=0) * scale
+        scale32 = np.float32(scale)
+        pred = np.concatenate([model.predict(x_test[s:s + batch]) for s in range(0, test_size, batch)], axis=0) * scale32
+        y_test = (y_test / scale32) * scale32                     # DeltaP/valid.py:126,159: normalised, then scaled back, in fp32
     else:
         # fields stay on the device: one metrics launch per batch, four numbers per case come back (U/valid.py:86-111)
         import torch
@@ -231,24 +301,25 @@ def evaluate(field: str, processed_folder: str, model_path: Optional[str] = None
             m, _colmax = ops.eval_metrics(y_dev, t_dev, scale)
             metrics.append(m)
         metrics = np.concatenate(metrics, axis=0)
-    csv_path = os.path.join(out_dir, f"error_test_{f['label']}.csv")
+    csv_path = os.path.join(out_dir, EVAL_CSV)
     with open(csv_path, "w", newline="") as fh:
         w = csv.writer(fh)
         if field == "DeltaP":
-            w.writerow(["Test ID", f"CFD ({f['unit']})", f"Predict ({f['unit']})", f"Error abs ({f['unit']})", "Error (%)"])
+            w.writerow(["Test ID", "Abs Error (Pa)", "Relative (%)"])                       # DeltaP/valid.py:148
         else:
             w.writerow(["Test ID", f"Error max ({f['unit']})", "Error max (%)", f"Error mean ({f['unit']})", "Cosine Similarity"])
         for ix in range(test_size):
             if field == "DeltaP":
-                yv, Yv = float(pred[ix, 0]), float(y_test[ix])
+                yv, Yv = np.float32(pred[ix, 0]), np.float32(y_test[ix])
                 err = abs(Yv - yv)
-                row = [ix, Yv, yv, err, err / abs(Yv) * 100 if Yv else float("nan")]
-                mean_err += err
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    row = [ix, float(err), float(err / Yv * np.float32(100))]               # :170-173
+                mean_err += float(err)
             else:
                 row = [ix] + [float(v) for v in metrics[ix]]
                 mean_err += row[3]
             w.writerow([str(v) for v in row])
             rows.append(row)
-    mean_err /= test_size
+    mean_err /= max(test_size, 1)
     print("Total average error: ", mean_err)
     return rows, mean_err

@@ -65,9 +65,13 @@ def test_train_resume_evaluate(field, tmp_path, monkeypatch):
     K.save_model(g, str(tmp_path / "again.keras"))
     w2 = K.load_model(str(tmp_path / "again.keras")).get_weights_dict()
     assert all(np.array_equal(w[k], w2[k]) for k in w)
-    rows, mean_err = cli.evaluate(field, folder, model=g, out_dir=str(tmp_path / "eval"))
-    assert len(rows) == 20 - int(0.9 * 20 + 1) and np.isfinite(mean_err)
-    assert any(p.suffix == ".csv" for p in (tmp_path / "eval").iterdir())
+    # <field>/valid.py: U scores the last 10 % of the folder, DeltaP the valid_indices.txt cases the training saved
+    rows, mean_err = cli.evaluate(field, folder, model=g, out_dir=str(tmp_path / "eval"), mode="valid")
+    assert len(rows) == (20 - int(0.9 * 20 + 1) if field == "U" else 2) and np.isfinite(mean_err)
+    assert (tmp_path / "eval" / cli.EVAL_CSV).exists()
+    # <field>/test.py: every case of the folder, scale from the training folder + train_indices.txt
+    rows, mean_err = cli.evaluate(field, folder, model=g, out_dir=str(tmp_path / "eval_t"), mode="test", train_folder=folder)
+    assert len(rows) == 20 and np.isfinite(mean_err)
 
 
 def test_keras_surface_shapes():

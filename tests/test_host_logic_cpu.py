@@ -252,3 +252,48 @@ def test_forward_chunked_host_logic(monkeypatch):
     calls.clear()
     monkeypatch.setenv("CFD_AMD_PREDICT_CHUNK", "16")     # one pass: the forward's own buffer is returned as is
     assert K._forward_chunked(forward, x[:3], True, seed=1) is not None and calls == [(3, 1, 0)]
+
+
+def test_eval_plans_select_and_scale_like_the_six_reference_scripts():
+    """each of U|P|DeltaP/{valid,test}.py scores its own set of cases with its own scale.
+    Restated here from the reference scripts (file:line in cli.EVAL_PLANS) on a toy folder of 20 cases."""
+    from cfd_amd import cli
+    n = 20
+    r = np.random.default_rng(5)
+    p_grids = [r.uniform(0, 100 * (i + 1), size=(4, 8)) for i in range(n)]       # case i's maximum grows with i
+    dps = [float(10 * (i + 1) + 0.123456789) for i in range(n)]
+    train_idx, valid_idx = np.array([3, 0, 17, 5, 9]), np.array([19, 2])
+    # U/valid.py:44-51: train_size = int(0.9 n + 1); the last n - train_size cases; no scale
+    assert cli.eval_selection("U", "valid", n) == [19]
+    assert cli.eval_selection("U", "valid", 100) == list(range(91, 100))
+    assert cli.eval_scale("U", "valid", None) == 1.0
+    with pytest.raises(ValueError):
+        cli.eval_selection("U", "valid", 5)
+    # U/test.py:77-86: train_size = 0 -> every case
+    assert cli.eval_selection("U", "test", n) == list(range(n)) and cli.eval_scale("U", "test", None) == 1.0
+    # P/valid.py:45-66,95: valid_indices.txt cases, 2 * max over the train_indices.txt cases of the same folder
+    assert cli.eval_selection("P", "valid", n, train_idx, valid_idx) == [19, 2]
+    want = 2.0 * max(p_grids[i].max() for i in train_idx)
+    assert cli.eval_scale("P", "valid", p_grids, train_idx) == want
+    # P/test.py:76-90,123-125,168: every case of the test folder, 2 * P_max of the TRAINING folder's train cases
+    assert cli.eval_selection("P", "test", 7, train_idx, None) == list(range(7))
+    assert cli.eval_scale("P", "test", p_grids, train_idx) == want
+    # DeltaP/valid.py:81-126,157: valid_indices.txt cases, P_max = float32 max of the train cases' DeltaP, factor 1
+    assert cli.eval_selection("DeltaP", "valid", n, train_idx, valid_idx) == [19, 2]
+    assert cli.eval_scale("DeltaP", "valid", dps, train_idx) == float(np.float32(dps[17]))
+    # DeltaP/test.py (a copy of P/test.py): every case, factor 2
+    assert cli.eval_selection("DeltaP", "test", 7, train_idx, None) == list(range(7))
+    assert cli.eval_scale("DeltaP", "test", dps, train_idx) == 2.0 * dps[17]
+    # indices that do not belong to the folder are refused, as is a missing index file
+    with pytest.raises(ValueError):
+        cli.eval_selection("P", "valid", 10, train_idx, valid_idx)
+    with pytest.raises(ValueError):
+        cli.eval_selection("P", "valid", n, train_idx, None)
+    with pytest.raises(ValueError):
+        cli.eval_scale("P", "test", p_grids[:10], train_idx)
+    # a one-case valid_indices.txt loads as a 0-d array (np.loadtxt)
+    assert cli.eval_selection("DeltaP", "valid", n, train_idx, np.array(4)) == [4]
+    # every plan names the folder its script hard-codes
+    assert cli.EVAL_PLANS[("P", "valid")]["folder"] == "./100_case_si_test/processed/"
+    assert cli.EVAL_PLANS[("DeltaP", "valid")]["folder"] == "./130_case/processed/"
+    assert cli.EVAL_PLANS[("U", "test")]["folder"] == "./30_case_duyanh/processed/"
