@@ -1,14 +1,20 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the CFD-surrogate hot path on MI355X (contract: task statement ④).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B] [--no-also]
 
 One "step" = one pass of the hot path over one batch of synthetic geometries resident in HBM.
 Workloads (BASELINE.json configs):
-  infer_pd_fp32   (default, configs[1]) P generator + DeltaP CNN batched inference, fp32 MFMA
-  infer_all_bf16  (configs[2])          U + P generators + DeltaP CNN batched inference, bf16 MFMA
-Cases are independent, so N GPUs shard them with no data-path collective ("scaling": "weak").
-Rank 0 prints ONE JSON line.
+  infer_pd_fp32   (headline, configs[1]) P generator + DeltaP CNN batched inference, fp32 MFMA
+  infer_all_bf16  (configs[2])           U + P generators + DeltaP CNN batched inference, bf16 MFMA
+  train_u_bf16    (configs[3])           U GAN training step, bf16, data parallel (B = 16 and 32 per GPU)
+  resample        (north_star item 1)    scattered points -> 64x512 grids, fp64, queries/s against the HBM roofline
+Rank 0 prints ONE JSON line: `value` etc. are the headline workload's; with no --workload the same line carries an
+`also` object with the other workloads, each with its own ms_per_step and live HIP-event roofline (and, for training,
+cpu_baseline).  Inference and the resample shard by case with no data-path collective ("scaling": "weak"); training
+exchanges gradients over RCCL every step.
+`--gpus N` with N > 1: under `python -m torch.distributed.run` (WORLD_SIZE set) this process is one rank; started
+plainly, it starts the N ranks itself as child processes (before anything touches a GPU) and relays rank 0's line.
 """
 import argparse
 import json
@@ -34,6 +40,30 @@ WORKLOADS = {
     "train_u_bf16": dict(nets=["U", "D"], dtype="bf16", batch=16, train=True),
     "train_u_fp32": dict(nets=["U", "D"], dtype="f32", batch=4, train=True),
 }
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` started plainly: start N ranks as fresh child processes (nothing in this process has
+    touched a GPU: torch.cuda.device_count() does not initialise one) and relay their output; rank 0 prints the line."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
 
 
 def dist_setup(n_gpus):
@@ -182,43 +212,14 @@ def pmc_traffic(workload):
     return round(b / n), (round(mb, 4) if mb is not None else None)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="infer_pd_fp32", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    rank, world, local = dist_setup(args.gpus)
-    wl = WORKLOADS[args.workload]
-    B = args.batch or wl["batch"]
-    tdt = torch.float32 if wl["dtype"] == "f32" else torch.bfloat16
-
-    from cfd_amd import ops, synthetic
-    # synthetic geometries of the reference shape, resident in HBM before the timed region
-    xs, us, _ = synthetic.model_batch([rank * B + i for i in range(B)])
-    x = torch.from_numpy(xs).cuda()
-    train = wl.get("train", False)
-    if train:
-        job = TrainJob(tdt)
-        y = torch.from_numpy(us).cuda()
-        models = None
-
-        def run_step(_m, xx, step, sample0):   # noqa: F811  (same signature as the inference step)
-            job.step(xx, y, step, sample0)
-    else:
-        run_step = globals()["run_step"]
-        models = build_nets(wl["nets"], tdt)
-
-    for s in range(args.warmup):
-        run_step(models, x, s, rank * B)
+def timed_steps(step_fn, steps, warmup, world):
+    """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks; -> seconds"""
+    for s in range(warmup):
+        step_fn(s)
     barrier(world)
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        run_step(models, x, args.warmup + s, rank * B)
+    for s in range(steps):
+        step_fn(warmup + s)
     barrier(world)
     dt = time.perf_counter() - t0
     if world > 1:
@@ -226,8 +227,34 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    return dt
 
-    # ---- roofline of the dominant kernel (igemm): HIP events around every launch, same workload
+
+def run_model_workload(name, B, steps, warmup, rank, world, cpu_base):
+    """one of the model workloads -> the fields of its JSON object (every rank runs it; rank 0 reports)"""
+    from cfd_amd import ops, synthetic
+    wl = WORKLOADS[name]
+    B = B or wl["batch"]
+    tdt = torch.float32 if wl["dtype"] == "f32" else torch.bfloat16
+    # synthetic geometries of the reference shape, resident in HBM before the timed region
+    xs, us, _ = synthetic.model_batch([rank * B + i for i in range(B)])
+    x = torch.from_numpy(xs).cuda()
+    train = wl.get("train", False)
+    if train:
+        job = TrainJob(tdt)
+        y = torch.from_numpy(us).cuda()
+
+        def step_fn(step):
+            job.step(x, y, step, rank * B)
+    else:
+        models = build_nets(wl["nets"], tdt)
+
+        def step_fn(step):
+            run_step(models, x, step, rank * B)
+
+    dt = timed_steps(step_fn, steps, warmup, world)
+
+    # ---- roofline of the dominant kernels (the MFMA implicit GEMMs): HIP events around every launch, same workload
     # (a training step holds collectives, so every rank runs this pass when training; rank 0 reports it)
     roof = None
     if rank == 0 or (train and world > 1):
@@ -240,38 +267,125 @@ def main():
         c1.record()
         torch.cuda.synchronize()
         head_start = int(1_000_000 * 4.0 / max(c0.elapsed_time(c1), 1e-3))       # ~4 ms
+        n_roof = min(steps, 5)
         with ops.KernelTimer() as kt:
-            for s in range(min(args.steps, 5)):
+            for s in range(n_roof):
                 torch.cuda._sleep(head_start)
-                run_step(models, x, 1000 + s, rank * B)
+                step_fn(1000 + s)
         sm = kt.summary()
         achieved = sm["total_flops"] / (sm["total_ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[wl["dtype"]]
         # the committed PMC passes were taken at the workload's default batch; they say nothing about another one
-        traffic, busy = pmc_traffic(args.workload) if B == wl["batch"] else (None, None)
+        traffic, busy = pmc_traffic(name) if B == wl["batch"] else (None, None)
         roof = dict(bound="mfma", kernel="igemm256_kernel+igemm_kernel" + ("+wgrad_kernel" if train else ""),
                     achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
                     frac=round(achieved / peak, 4), traffic=traffic, mfma_busy_frac_pmc=busy,
-                    launches_per_step=sm["launches"] // min(args.steps, 5),
+                    launches_per_step=sm["launches"] // n_roof,
                     avg_launch_us=round(sm["total_ms"] * 1e3 / sm["launches"], 2))
+    out = {"value": round(world * B * steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": steps,
+           "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "dtype": wl["dtype"],
+           "config": {"workload": name, "nets": wl["nets"], "per_gpu_batch": B, "global_batch": B * world,
+                      "grid": "64x512", "parallelism": (f"dp{world}, RCCL reduce-scatter + sharded Adam + all-gather"
+                                                        if train else f"case-sharded x{world}, no collectives")},
+           "roofline": roof}
+    if cpu_base and rank == 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline_train() if train else cpu_baseline(wl["nets"])
+    return out
 
+
+def run_resample_workload(steps, warmup, rank, world, cpu_base, ncase=256):
+    """north_star item 1 / SURVEY.md §8(d): `ncase` synthetic scattered cases (101 slices x 21 points, jittered) ->
+    64x512 grids per step, inputs and outputs resident in HBM; queries/s = pixels resampled per second."""
+    from cfd_amd import ops, synthetic
+    H, W = 64, 512
+    cases = [synthetic.scattered_case(rank * ncase + i, jitter=0.2) for i in range(ncase)]
+    job = ops.ResampleJob(cases, H, W)
+    dt = timed_steps(lambda _s: job.run(), steps, warmup, world)
+    roof = None
     if rank == 0:
-        value = world * B * args.steps / dt
-        out = {
-            "metric": "surrogate samples/sec (infer + train) at 1/2/4/8 GPUs; field rel-err vs CPU ref",
-            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
-            "config": {"workload": args.workload, "nets": wl["nets"], "per_gpu_batch": B,
-                       "global_batch": B * world, "grid": "64x512", "parallelism": (f"dp{world}, RCCL gradient all-reduce" if train else f"case-sharded x{world}, no collectives")},
-            "roofline": roof,
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_train() if train else cpu_baseline(wl["nets"])
+        n_roof = min(steps, 5)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_roof)]
+        torch.cuda.synchronize()
+        for a, b in ev:
+            a.record()
+            job.run()
+            b.record()
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in ev) / n_roof
+        gbs = job.algorithmic_bytes() / (ms * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel="wall_slices+wall_interp+nearest_kernel (one cfd_resample_nearest call)",
+                    achieved=round(gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 5),
+                    traffic=None, algorithmic_bytes_per_launch=job.algorithmic_bytes(), avg_launch_us=round(ms * 1e3, 2))
+    out = {"value": round(world * ncase * H * W * steps / dt, 1), "unit": "queries/s", "n_gpus": world, "steps": steps,
+           "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "dtype": "f64",
+           "cases_per_s": round(world * ncase * steps / dt, 1),
+           "config": {"workload": "resample", "cases_per_step": ncase, "points_per_case": int(job.n_points // ncase),
+                      "grid": "64x512", "parallelism": f"case-sharded x{world}, no collectives"},
+           "roofline": roof}
+    if cpu_base and rank == 0 and world == 1:
+        from oracle import resample as OR
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 10.0 and n < len(cases):
+            OR.resample(cases[n], H, W)
+            n += 1
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=round(n * H * W / el, 1), unit="queries/s", cores=1, kind="port",
+                                   sample=f"{n} of the same cases through oracle/resample.py (numpy + scipy cKDTree, one thread)")
+    return out
+
+
+def free_device_memory():
+    import gc
+    from cfd_amd import ops
+    gc.collect()
+    ops._ws_cache.clear()
+    torch.cuda.empty_cache()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS) + ["resample"])
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="only the headline workload")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    rank, world, local = dist_setup(args.gpus)
+    cpu_base = not args.no_cpu_baseline
+    name = args.workload or "infer_pd_fp32"
+    if name == "resample":
+        res = run_resample_workload(args.steps, args.warmup, rank, world, cpu_base)
+    else:
+        res = run_model_workload(name, args.batch, args.steps, args.warmup, rank, world, cpu_base)
+    out = {"metric": "surrogate samples/sec (infer + train) at 1/2/4/8 GPUs; field rel-err vs CPU ref"}
+    out.update({k: res[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")})
+    out.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": res["dtype"],
+                "data": "synthetic", "config": res["config"], "roofline": res["roofline"]})
+    if "cpu_baseline" in res:
+        out["cpu_baseline"] = res["cpu_baseline"]
+    if args.workload is None and not args.no_also:
+        # the other BASELINE configs under the same clock: fewer steps each, same contract (warm-up, barrier, max over ranks)
+        also = {}
+        k, w = max(3, min(args.steps, 10)), min(args.warmup, 2)
+        for key, wname, B, base in (("infer_all_bf16", "infer_all_bf16", 0, False),
+                                    ("train_u_bf16", "train_u_bf16", 16, cpu_base),
+                                    ("train_u_bf16_b32", "train_u_bf16", 32, False)):
+            free_device_memory()
+            also[key] = run_model_workload(wname, B, k, w, rank, world, base)
+        free_device_memory()
+        also["resample"] = run_resample_workload(k, w, rank, world, cpu_base)
+        out["also"] = also
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
-        barrier(world)                      # rank 0 ran the roofline pass alone: leave together
+        barrier(world)
         dist.destroy_process_group()
 
 

@@ -12,7 +12,11 @@ struct ArgMax {
   int i;
 };
 __device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {
-  // numpy.argmax: first occurrence of the maximum in row-major order
+  // numpy.argmax / ndarray.max: first occurrence of the maximum in row-major order, and a NaN IS the maximum (the
+  // first NaN wins): a diverged model's all-NaN prediction then reports NaN, as the reference would, instead of
+  // leaving the index at its start value
+  const bool an = a.v != a.v, bn = b.v != b.v;
+  if (an || bn) return (bn && (!an || b.i < a.i)) ? b : a;
   return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
 
@@ -23,7 +27,7 @@ __global__ __launch_bounds__(256) void eval_metrics_kernel(const float *__restri
   const float *y = pred + (size_t)c * H * W, *Y = target + (size_t)c * H * W;
   double esum = 0.0, cos_sum = 0.0;
   int cos_n = 0;
-  ArgMax am = {-1.f, 0x7fffffff};
+  ArgMax am = {-1.f, 0};      // every |Y - y| is >= 0 or NaN, so the start value never survives; index 0 keeps Y[am.i] in bounds regardless
   for (int r = wave; r < H; r += 4) {
     double dot = 0.0, na = 0.0, nb = 0.0;
     int nz = 0;
@@ -74,7 +78,10 @@ __global__ __launch_bounds__(256) void eval_metrics_kernel(const float *__restri
   if (colmax)
     for (int j = tid; j < W; j += 256) {
       float m = 0.f;
-      for (int r = 0; r < H; ++r) m = fmaxf(m, fabsf(Y[r * W + j] - y[r * W + j] * scale));
+      for (int r = 0; r < H; ++r) {
+        const float e = fabsf(Y[r * W + j] - y[r * W + j] * scale);
+        m = (e > m || e != e) ? e : m;            // ndarray.max(axis=0) propagates NaN (fmaxf would drop it)
+      }
       colmax[(size_t)c * W + j] = m;
     }
 }

@@ -152,7 +152,16 @@ class Model:
             print_fn(f"  {name:28s} {str(s.keras_shape):24s} {s.numel:>12,d}")
         print_fn(f"Total params: {self.count_params():,d}")
 
+    def sync_state(self) -> None:
+        """Under data parallelism the sharded optimizer step (trainer._DP) leaves the fp32 master weights and Adam
+        moments of the chunks other ranks own stale: bring them up to date.  COLLECTIVE -- every rank calls it (every
+        rank runs the same script, so every rank saves).  A no-op for one process."""
+        for tr in (getattr(self, "_trainer", None), getattr(self, "_gan_trainer", None)):
+            if tr is not None:
+                tr.sync_state()
+
     def get_weights_dict(self):
+        self.sync_state()
         return self.net.params.to_keras()
 
     def set_weights_dict(self, w):
@@ -219,10 +228,26 @@ class DiscriminatorModel(Model):
 
     def _tr(self):
         if self._trainer is None:
-            # compiled in define_discriminator BEFORE define_gan freezes the conv layers, so D's own step
-            # trains everything (Keras-2 / pix2pix behaviour; see oracle/keras_semantics.py)
-            self._trainer = trainer.DiscriminatorTrainer(self.net, lr=2e-3, beta_1=0.5, train_convs=True)
+            self._trainer = trainer.DiscriminatorTrainer(self.net, lr=2e-3, beta_1=0.5, train_convs=self.d_step_trains_convs())
         return self._trainer
+
+    def d_step_trains_convs(self) -> bool:
+        """Does d_model.train_on_batch update D's convolutions?  define_discriminator compiles D BEFORE define_gan
+        sets `layer.trainable = False` on its conv layers (U/models/generator.py:79-81).
+          CFD_AMD_D_FREEZE=compile (default): trainability is what it was at compile() -- the Keras-2 snapshot and the
+              pix2pix intent: D trains fully in its own step, frozen inside the composite.
+          CFD_AMD_D_FREEZE=call: `layer.trainable` is read when the first train_on_batch builds the step -- the
+              Keras-3 reading of the same script (the reference's comments name tensorflow 2.16-2.18): D's own step then
+              updates only its BatchNorm gamma/beta once define_gan has run.
+        Which of the two real Keras does cannot be checked here (no TensorFlow: parity unpinned); the
+        choice is stored in the checkpoint's config.json."""
+        mode = getattr(self, "_d_freeze", None) or os.environ.get("CFD_AMD_D_FREEZE", "compile").lower()
+        if mode not in ("compile", "call"):
+            raise ValueError("CFD_AMD_D_FREEZE must be 'compile' or 'call'")
+        self._d_freeze = mode
+        if mode == "compile":
+            return True
+        return all(l.trainable for l in self.layers if isinstance(l, Conv2D))
 
     @staticmethod
     def _label(y) -> float:
@@ -253,6 +278,7 @@ class GanModel(Model):
         self.compiled = True
         self._trainer = trainer.GanTrainer(g_model.net, d_model.net, lr=4e-4, beta_1=0.5, field_loss=ops.MAE,
                                            field_weight=100.0)
+        g_model._gan_trainer = d_model._gan_trainer = self._trainer      # who else updates their weights (sync_state)
 
     @property
     def output_shape(self):
@@ -396,7 +422,13 @@ def save_model(model, filepath, overwrite=True, include_optimizer=True):
     cfg = {"format": FORMAT, "class_name": model.kind, "image_shape": list(model.image_shape),
            "compute_dtype": str(_dtype()).replace("torch.", "")}
     weights, opt = {}, {}
+    model.sync_state()
+    if isinstance(model, DiscriminatorModel):
+        cfg["d_freeze"] = getattr(model, "_d_freeze", None) or os.environ.get("CFD_AMD_D_FREEZE", "compile").lower()
+        cfg["d_convs_trainable"] = all(l.trainable for l in model.layers if isinstance(l, Conv2D))
     if isinstance(model, GanModel):
+        model.g_model.sync_state()
+        model.d_model.sync_state()
         cfg["arch"] = model.g_model.arch
         weights.update({"g/" + k: v for k, v in model.g_model.get_weights_dict().items()})
         weights.update({"d/" + k: v for k, v in model.d_model.get_weights_dict().items()})
@@ -440,6 +472,12 @@ def load_model(filepath, compile=True, custom_objects=None):
     elif kind == "discriminator":
         m = DiscriminatorModel(shape)
         m.set_weights_dict(w)
+        if cfg.get("d_freeze"):
+            m._d_freeze = cfg["d_freeze"]
+            if not cfg.get("d_convs_trainable", True):
+                for l in m.layers:                      # saved after define_gan froze the convolutions: restore that
+                    if not isinstance(l, BatchNormalization):
+                        l.trainable = False
         if compile and o:
             _load_opt(m._tr().opt, o, "opt/")
     elif kind == "cnn":

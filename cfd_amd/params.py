@@ -5,8 +5,10 @@ dtype for the MFMA operands.  Keras layouts appear only at the interchange bound
 
 Order inside the flat buffer: trainable non-BN tensors, then BN gamma/beta (one contiguous range,
 because `define_gan` leaves exactly those of D trainable, U/models/generator.py:79-81), then the
-non-trainable moving statistics.  Every tensor starts on a 64-element boundary so that 16-B vector
-loads (bias, gamma) and a single fused Adam launch over the trainable prefix stay aligned.
+non-trainable moving statistics.  Every tensor starts on a 512-element boundary: 16-B vector loads (bias,
+gamma) and a single fused Adam launch over the trainable prefix stay aligned, and every range between
+two layer boundaries divides into 2, 4 or 8 chunks of whole 64-element groups -- the reduce-scatter /
+sharded-Adam / all-gather data-parallel step (trainer._DP) splits such ranges by rank.
 """
 from __future__ import annotations
 
@@ -18,7 +20,7 @@ import torch
 
 from . import ops
 
-ALIGN = 64
+ALIGN = 512
 
 
 class Spec:

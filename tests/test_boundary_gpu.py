@@ -158,3 +158,25 @@ def test_predict_in_chunks_equals_one_pass(monkeypatch):
     monkeypatch.setenv("CFD_AMD_PREDICT_CHUNK", "3")
     g._seed = 77
     assert np.abs(g.predict(x) - whole).max() <= 1e-5 * np.abs(whole).max()
+
+
+@pytest.mark.parametrize("mode", ["compile", "call"])
+def test_discriminator_own_step_freeze_switch(mode, monkeypatch):
+    """define_gan sets trainable=False on D's conv layers AFTER D was compiled (U/models/generator.py:79-81).
+    CFD_AMD_D_FREEZE=compile (default, Keras-2 snapshot): D's own train_on_batch still updates its convolutions;
+    =call (Keras-3 reading): only BatchNorm gamma/beta move.  The composite never touches D's convolutions."""
+    from cfd_amd import keras_api as K, synthetic
+    monkeypatch.setenv("CFD_AMD_D_FREEZE", mode)
+    x, u, _ = synthetic.model_batch([0])
+    d = K.define_discriminator((64, 512, 1))
+    g = K.define_generator_P((64, 512, 1))
+    gan = K.define_gan(g, d, (64, 512, 1))
+    P = d.net.params
+    k0, g0 = P.m("c3.kernel").clone(), P.m("c3.bn.gamma").clone()
+    d.train_on_batch([x, u], np.ones((1, 4, 32, 1)))
+    assert d.d_step_trains_convs() == (mode == "compile")
+    assert (not bool((P.m("c3.kernel") == k0).all())) == (mode == "compile")
+    assert not bool((P.m("c3.bn.gamma") == g0).all())
+    k1 = P.m("c3.kernel").clone()
+    gan.train_on_batch([x], [np.ones((1, 4, 32, 1)), u])
+    assert bool((P.m("c3.kernel") == k1).all())

@@ -152,7 +152,7 @@ def test_dataset_cache_is_exact_and_keyed_by_content(tmp_path, monkeypatch):
         assert a.dtype == np.float64 and np.array_equal(a, b) and np.array_equal(a, c)
     monkeypatch.setattr(pd, "read_csv", real)
     first = sorted(os.listdir(folder))[0]
-    df = pd.read_csv(folder / first)
+    df = pd.read_csv(folder / first, float_precision="round_trip")
     df.loc[0, "p_convert"] += 1.0
     df.to_csv(folder / first, index=False)
     p3, _ = D.read_cases(str(folder), h, w, str(cache))

@@ -1,5 +1,6 @@
 """world_size-2 checks of the data-parallel plumbing on CPU (gloo): bucketed gradient all-reduce, the
-1/world scaling that Adam applies, and contiguous case sharding for inference.  The kernels themselves
+1/world scaling that Adam applies, the sharded step (reduce-scatter, Adam on the rank's chunks, all-gather) against the
+replicated one bit for bit, the initial broadcast of rank 0's parameters, and contiguous case sharding for inference.  The kernels themselves
 need a GPU; here the flat gradient buffers are plain CPU tensors."""
 import os
 import socket
@@ -17,11 +18,109 @@ def _free_port():
     return p
 
 
+class _Spec:
+    def __init__(self, offset):
+        self.offset = offset
+
+
+class _FakeParams:
+    """a CPU stand-in for params.ParamStore: flat fp32 master, bf16 compute copy, flat gradient; layer offsets on
+    512-element boundaries as ParamStore lays them out"""
+
+    def __init__(self, seed, bf16=True):
+        g = torch.Generator().manual_seed(seed)
+        self.n_main, self.n_trainable, self.n_total = 7 * 1024, 7 * 1024 + 512, 8 * 1024
+        self.specs = {"e1.kernel": _Spec(0), "e2.kernel": _Spec(512), "d1.kernel": _Spec(3 * 1024), "out.kernel": _Spec(6 * 1024)}
+        self.master = torch.randn(self.n_total, generator=g)
+        self.compute = self.master[:self.n_trainable].to(torch.bfloat16) if bf16 else self.master
+        self.grad = torch.zeros(self.n_trainable)
+        self.device = torch.device("cpu")
+
+    def refresh_compute(self):
+        if self.compute is not self.master:
+            self.compute.copy_(self.master[:self.n_trainable])
+
+    def refresh_transposed(self):
+        pass
+
+
+def _cpu_adam(w, g, m, v, wc, alpha, b1, b2, eps, grad_scale):
+    """what cfd_adam_step computes (include/cfd_amd.h), elementwise, for the plumbing test"""
+    gg = g * grad_scale
+    m.add_((gg - m) * (1 - b1))
+    v.add_((gg * gg - v) * (1 - b2))
+    w.sub_(alpha * m / (v.sqrt() + eps))
+    if wc is not None:
+        wc.copy_(w)
+
+
+def _run_steps(rank, world, shard, bf16, grad_bf16=False, steps=3):
+    from cfd_amd import ops, trainer
+    ops.adam_step = _cpu_adam
+    P = _FakeParams(seed=100 + rank, bf16=bf16)                    # replicas start DIFFERENT ...
+    opt = trainer.Adam(P, 0, P.n_trainable, 1e-2, 0.5)
+    dp = trainer._DP(shard=shard, shard_min=1024, grad_bf16=grad_bf16)
+    trainer.sync_from_rank0(dp, P, [opt])                           # ... and must leave here equal
+    for step in range(steps):
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        P.grad.copy_(torch.randn(P.n_trainable, generator=g))
+        bk = trainer.BackwardBuckets(dp, P, min_elems=2048)
+        for layer in ("out", "d1", "e2", "e1"):
+            bk.ready(layer)
+        bk.finish()
+        dp.wait()
+        segs = dp.take(P, opt.lo, opt.hi)
+        opt.step(dp.grad_scale, segs)
+        dp.gather_params(P, segs)
+    compute_after = P.compute.clone()
+    stale = None
+    if shard and bf16:
+        a, b = sorted(dp.partition[id(P)])[0]
+        ca, cb = dp.chunk(a, b)
+        other = a if ca != a else cb                                # an element another rank owns
+        stale = P.master[other].item()
+    dp.sync_state(P, [opt])
+    return P, opt, dp, compute_after, stale
+
+
+def _sharded_step_equals_replicated(rank, world):
+    """reduce-scatter + Adam on this rank's chunks + all-gather == all-reduce + the same Adam on every rank, bit for
+    bit: compute copy right after the step, master and moments after sync_state; replicas that start from different
+    weights are equalised by sync_from_rank0"""
+    ok = True
+    for bf16 in (True, False):
+        Pr, optr, dpr, cr, _ = _run_steps(rank, world, False, bf16)
+        Ps, opts_, dps, cs, stale = _run_steps(rank, world, True, bf16)
+        sharded = {(a, b) for a, b in dps.partition[id(Ps)]}
+        ok = ok and len(sharded) >= 2 and not dpr.partition            # the sharded form really ran (and only there)
+        ok = ok and torch.equal(cr, cs)
+        ok = ok and torch.equal(Pr.master, Ps.master) and torch.equal(optr.m, opts_.m) and torch.equal(optr.v, opts_.v)
+        ok = ok and optr.t == opts_.t == 3
+        # rank 0's initial weights reached everyone: every rank's result equals rank 0's
+        ref = Ps.master.clone()
+        import torch.distributed as dist
+        dist.broadcast(ref, src=0)
+        ok = ok and torch.equal(ref, Ps.master)
+        if bf16:      # before sync_state, a chunk another rank owns held the stale master (that is what sync repairs)
+            a, b = sorted(sharded)[0]
+            ca, cb = dps.chunk(a, b)
+            other = a if ca != a else cb
+            ok = ok and stale != Ps.master[other].item()
+    # bf16 gradient exchange: same plumbing, half the bytes; within bf16 rounding of the fp32 exchange
+    try:
+        Pb, _o, _d, _c, _s = _run_steps(rank, world, True, True, grad_bf16=True)
+        Pr, _o, _d, _c, _s = _run_steps(rank, world, False, True)
+        ok = ok and float((Pb.master - Pr.master).abs().max()) < 0.1 and not torch.equal(Pb.master, Pr.master)
+    except RuntimeError as e:        # a backend without 16-bit reductions: the flag is optional
+        print("bf16 gradient exchange not exercised on this backend:", e)
+    return ok
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from cfd_amd import trainer, sharding
-    dp = trainer._DP(bucket_elems=1000)            # several buckets
+    dp = trainer._DP(bucket_elems=1000, shard=False)            # several buckets, replicated form
     g = torch.arange(4096, dtype=torch.float32) * (rank + 1)
     dp.reduce_async(g)
     dp.wait()
@@ -34,6 +133,7 @@ def _worker(rank, world, port, out):
 
     class _P:
         n_main, n_trainable = 6000, 6400
+        master = torch.zeros(6400)
         specs = {"e1.kernel": _Spec(0), "e2.kernel": _Spec(1024), "d1.kernel": _Spec(3000), "out.kernel": _Spec(5500)}
         grad = torch.ones(6400, dtype=torch.float32) * (rank + 1)
     bk = trainer.BackwardBuckets(dp, _P, min_elems=2000)
@@ -46,6 +146,7 @@ def _worker(rank, world, port, out):
     ok = ok and spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans[:-2], spans[1:-1])) \
         and spans[-2][1] == 6000 and spans[-1] == (6000, 6400) and bk.sent[0] == (3000, 6000) \
         and bool((_P.grad == tot).all())
+    ok = ok and _sharded_step_equals_replicated(rank, world)
     lo, hi = sharding.case_range(10001, rank, world)
     out.put((rank, ok, lo, hi))
     dist.destroy_process_group()

@@ -7,7 +7,8 @@ bench.py, bucketed all-reduce launched from inside the backward, 1/world scaling
 statistics) against a stand-in for torch.distributed whose all_reduce is a rendezvous of the two threads; only one
 thread runs at a time, the hand-over happens inside the collectives.  The transport itself (torch.distributed) is
 covered by tests/test_dp_gloo.py.  Checked: one sample per rank leaves the same weights as one process stepping on
-both samples, and both ranks end bit-identical."""
+both samples, and both ranks end bit-identical -- for the replicated step (all-reduce) and for the sharded one
+(reduce-scatter, Adam on the rank's chunks, all-gather; trainer._DP)."""
 import threading
 
 import numpy as np
@@ -30,17 +31,16 @@ class VirtualWorld:
     def get_world_size(self):
         return self.world
 
-    def all_reduce(self, t, async_op=False):
+    def _rendezvous(self, kind, payload, combine):
+        """every rank deposits `payload`; one of them runs combine(list of payloads by rank); all leave together"""
         rank = self.local.rank
         torch.cuda.synchronize()
-        self.slots[rank] = t
-        self.calls[rank].append(t.numel())
+        self.slots[rank] = payload
+        self.calls[rank].append((kind, payload[0].numel()))
         self.run_lock.release()
         if self.barrier.wait(timeout=120) == 0:
-            assert len({s.numel() for s in self.slots}) == 1, "ranks disagree on a collective's size"
-            total = torch.stack([s for s in self.slots]).sum(0)
-            for s in self.slots:
-                s.copy_(total)
+            assert len({s[0].numel() for s in self.slots}) == 1, "ranks disagree on a collective's size"
+            combine(self.slots)
             torch.cuda.synchronize()
         self.barrier.wait(timeout=120)
         self.run_lock.acquire()
@@ -50,15 +50,39 @@ class VirtualWorld:
                 return True
         return _Done()
 
+    def all_reduce(self, t, async_op=False):
+        def combine(slots):
+            total = torch.stack([s[0] for s in slots]).sum(0)
+            for s in slots:
+                s[0].copy_(total)
+        return self._rendezvous("all_reduce", (t,), combine)
 
-def _make(world=None):
+    def reduce_scatter_tensor(self, out, inp, async_op=False):
+        def combine(slots):
+            total = torch.stack([s[0] for s in slots]).sum(0)
+            c = total.numel() // self.world
+            for r, s in enumerate(slots):
+                assert s[1].numel() == c
+                s[1].copy_(total[r * c:(r + 1) * c])
+        return self._rendezvous("reduce_scatter", (inp, out), combine)
+
+    def all_gather_into_tensor(self, out, inp, async_op=False):
+        def combine(slots):
+            whole = torch.cat([s[0] for s in slots])
+            for s in slots:
+                assert s[1].numel() == whole.numel()
+                s[1].copy_(whole)
+        return self._rendezvous("all_gather", (inp, out), combine)
+
+
+def _make(world=None, rank=0, shard=False, dtype=torch.float32):
     from cfd_amd import nets, trainer
-    g = nets.Generator("P", dtype=torch.float32, seed=5)
-    d = nets.Discriminator(dtype=torch.float32, seed=6)
+    g = nets.Generator("P", dtype=dtype, seed=5)
+    d = nets.Discriminator(dtype=dtype, seed=6)
     dtr, gtr = trainer.DiscriminatorTrainer(d), trainer.GanTrainer(g, d)
     if world is not None:
         for tr in (dtr, gtr):
-            tr.dp.dist, tr.dp.world, tr.dp.stream = world, world.world, None
+            tr.dp.dist, tr.dp.world, tr.dp.stream, tr.dp.rank, tr.dp.shard = world, world.world, None, rank, shard
     return g, d, dtr, gtr
 
 
@@ -71,12 +95,15 @@ def _step(g, d, dtr, gtr, x, u, sample0):
     torch.cuda.synchronize()
 
 
-def test_dp_world2_equals_one_process_on_both_samples():
+@pytest.mark.parametrize("shard", [False, True])
+def test_dp_world2_equals_one_process_on_both_samples(shard):
+    """shard=False: bucketed all-reduce, replicated Adam.  shard=True: reduce-scatter, Adam on the rank's chunks (the real
+    kernel on chunk views of the flat buffers), all-gather of the compute copy, sync_state before the comparison."""
     from cfd_amd import synthetic
     xs, us, _ = synthetic.model_batch([0, 1])
     xs, us = torch.from_numpy(xs).cuda(), torch.from_numpy(us).cuda()
     vw = VirtualWorld(2)
-    ranks = [_make(vw) for _ in range(2)]
+    ranks = [_make(vw, r, shard) for r in range(2)]
     errors = []
 
     def run(rank):
@@ -84,6 +111,12 @@ def test_dp_world2_equals_one_process_on_both_samples():
         vw.run_lock.acquire()
         try:
             _step(*ranks[rank], xs[rank:rank + 1], us[rank:rank + 1], sample0=rank)
+            if shard:
+                g_, d_, dtr_, gtr_ = ranks[rank]
+                kinds = {k for k, _n in vw.calls[rank]}
+                assert {"reduce_scatter", "all_gather", "all_reduce"} <= kinds, kinds
+                dtr_.sync_state()
+                gtr_.sync_state()
         except BaseException as e:      # noqa: BLE001 -- reported by the main thread
             errors.append((rank, repr(e)))
             vw.barrier.abort()
@@ -113,3 +146,22 @@ def test_dp_world2_equals_one_process_on_both_samples():
             assert float((diff > 0.5 * lr).double().mean()) <= 1e-3, (name, rank)
         # both ranks hold the same state bit for bit, D's rank-averaged moving statistics included
         assert torch.equal(ranks[0][k].params.master, ranks[1][k].params.master), name
+
+
+def test_bench_starts_two_nccl_ranks_by_itself():
+    """`python bench.py --gpus 2` (no launcher): two child ranks over RCCL, the sharded data-parallel training step,
+    one JSON line from rank 0 with n_gpus = 2.  Needs two GPUs: RCCL refuses two ranks on one device, so this skips on
+    the one-GPU test box (the transport is covered on CPU by tests/test_dp_gloo.py, the step above by virtual ranks)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "train_u_bf16", "--batch", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["value"] > 0

@@ -404,6 +404,28 @@ def test_eval_metrics(H, W):
     assert e.shape == (0, 4)
 
 
+def test_eval_metrics_nan_prediction():
+    """a diverged model (NaN prediction, all of a case or one pixel): numpy's max / argmax treat NaN as the maximum,
+    so the reference writes a row of NaN; the kernel must do the same and never index with its start value"""
+    from cfd_amd import ops
+    from oracle import metrics as M
+    rng = np.random.default_rng(3)
+    H, W = 8, 96
+    y = rng.random((3, H, W), dtype=np.float32)
+    Y = rng.random((3, H, W), dtype=np.float32) + 0.5
+    y[0] = np.nan
+    y[1, 5, 17] = np.nan
+    y[1, 6, 3] = np.nan
+    m, col = ops.eval_metrics(torch.from_numpy(y).cuda(), torch.from_numpy(Y).cuda(), 1.0)
+    for c in range(3):
+        emax, pct, emean, cos, colmax = M.field_metrics(y[c], Y[c])
+        for got, want in ((m[c, 0], emax), (m[c, 1], pct), (m[c, 2], emean)):
+            assert (np.isnan(want) and np.isnan(got)) or abs(got - want) <= 1e-5 * abs(want)
+        assert np.array_equal(col[c], colmax, equal_nan=True)
+    assert np.isnan(m[0, :3]).all() and np.isnan(m[1, :3]).all() and np.isfinite(m[2]).all()
+    assert np.isnan(col[1, 17]) and np.isnan(col[1, 3]) and np.isfinite(col[1, 4])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,C", [(1, 16, 128, 512), (2, 7, 9, 64), (3, 4, 32, 2048)])
 def test_bn_stats_then_apply(B, H, W, C, dtype):
