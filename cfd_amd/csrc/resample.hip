@@ -11,60 +11,160 @@
 // in numpy/scipy's x86-64 builds, so the argmin and the interpolated wall are the same doubles.
 // Equidistant source points resolve to the LOWEST index (scipy's choice is traversal dependent).
 //
-// Layout: points stay AoS [n][5] in HBM (40 B rows); the nearest kernel stages (y,z) pairs of a tile
-// of points into LDS once per block and every thread (one pixel each) scans them with broadcast
-// reads; the 5 output columns of a pixel are written as one 40-B row, rows contiguous across lanes.
+// HBM-bound by contract (40 B per input point + 40 B per output pixel), so the search must not cost
+// H*W*N distance evaluations: the points of a case are binned into a uniform cell grid (about two
+// points per cell, cells square in metres) and every pixel searches rings of cells around its own
+// until no unvisited cell can hold a nearer -- or equally near -- point.  The stop test is exact in
+// ROUNDED arithmetic: a point outside the visited box [cy0..cy1] x [cz0..cz1] lies beyond one of the
+// box's boundary coordinates b, and because fp64 subtraction, squaring and addition are monotone its
+// rounded distance is >= (b - q)*(b - q) computed the same way; the search stops only when the best
+// distance is STRICTLY below the smallest such bound, so ties (lowest index wins) are never cut off.
+// The result is therefore the same argmin the brute-force scan gives, bit for bit, for any grid.
+//
+// Kernels of one call (all cases at once; ragged cases via the offsets array):
+//   resample_init      accumulators (+-inf encodings, zero counts)
+//   points_pass        per point: bounding box of its case (wave-aggregated atomics) and the min/max of y in
+//                      every z slice it is near (replaces 101 scans of the table per case)
+//   case_setup         per case: decode the slices, np.interp the wall to the W columns, choose the cell grid
+//   bin_count / bin_scan / bin_scatter   counting sort of the points by cell (cell lists)
+//   nearest_kernel     8 x 32-pixel tiles; ring search; the tile's 5-column rows leave through LDS as
+//                      contiguous runs (whole 128-B lines), not as five 8-B stores at 40-B lane stride
 #include "common.h"
 
 namespace cfd {
 
-struct ResampleWs {          // per case, in the caller's workspace
-  // [S] ymin, [S] ymax, [W] ylo, [W] yhi, then 1 int status
+__device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+__device__ __forceinline__ double dinf() { return __longlong_as_double(0x7ff0000000000000LL); }
+
+// order-preserving map double -> uint64 (for atomicMin / atomicMax on doubles)
+__device__ __forceinline__ unsigned long long enc(double d) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double dec(unsigned long long e) {
+  const unsigned long long u = (e >> 63) ? (e & 0x7fffffffffffffffULL) : ~e;
+  return __longlong_as_double((long long)u);
+}
+
+// ---- workspace layout (host and device agree through this struct) -------------------------------------
+struct RsLayout {
+  int ncase, W, S;
+  int64_t total;        // points of all cases
+  int64_t wall_stride;  // doubles per case in the wall block: [S] lo, [S] hi, [W] ylo, [W] yhi, 2 status
+  // byte offsets from the workspace base
+  int64_t o_wall, o_sacc, o_scnt, o_bbox, o_grid, o_bnd, o_start, o_cnt, o_cell, o_syz, o_sidx, bytes;
 };
 
-__device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+static inline int64_t align16(int64_t v) { return (v + 15) & ~(int64_t)15; }
 
-// one block per (slice, case): min/max of y over points with |z - zs| < tol1, else tol2
-__global__ __launch_bounds__(256) void wall_slices_kernel(const double *__restrict__ pts,
-                                                         const int64_t *__restrict__ offs,
-                                                         const double *__restrict__ zs, int S, double tol1,
-                                                         double tol2, double *__restrict__ ws, int64_t ws_stride) {
-  const int s = blockIdx.x, cs = blockIdx.y;
-  const int64_t beg = offs[cs], end = offs[cs + 1];
-  const double zv = zs[s];
-  const double inf = __longlong_as_double(0x7ff0000000000000LL);
-  double mn1 = inf, mx1 = -inf, mn2 = inf, mx2 = -inf;
-  int c1 = 0, c2 = 0;
-  for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
-    const double y = pts[i * 5 + 1], z = pts[i * 5 + 2];
-    const double d = fabs(z - zv);
-    if (d < tol1) { mn1 = fmin(mn1, y); mx1 = fmax(mx1, y); ++c1; }
-    if (d < tol2) { mn2 = fmin(mn2, y); mx2 = fmax(mx2, y); ++c2; }
+static RsLayout rs_layout(int ncase, int W, int S, int64_t total) {
+  RsLayout L;
+  L.ncase = ncase; L.W = W; L.S = S; L.total = total;
+  L.wall_stride = 2 * (int64_t)S + 2 * (int64_t)W + 2;
+  const int64_t cells = total + 64 * (int64_t)ncase;    // sum over cases of cap_i = max(64, N_i) <= this
+  int64_t o = 0;
+  L.o_wall = o;  o = align16(o + (int64_t)ncase * L.wall_stride * 8);
+  L.o_sacc = o;  o = align16(o + (int64_t)ncase * 4 * S * 8);            // uint64 [ncase][4][S]: mn1 mx1 mn2 mx2
+  L.o_scnt = o;  o = align16(o + (int64_t)ncase * 4 * S * 4);            // int    [ncase][4][S]: n1 n2 nan1 nan2
+  L.o_bbox = o;  o = align16(o + (int64_t)ncase * 4 * 8);                // uint64 [ncase][4]: ymin ymax zmin zmax
+  L.o_grid = o;  o = align16(o + (int64_t)ncase * 8 * 8);                // double [ncase][8]: ny nz y0 z0 invy invz - -
+  L.o_bnd = o;   o = align16(o + (cells + 3 * (int64_t)ncase) * 8);      // double boundaries, per case ny+1 + nz+1
+  L.o_start = o; o = align16(o + (cells + (int64_t)ncase) * 4);          // int cell_start, per case ncell+1
+  L.o_cnt = o;   o = align16(o + cells * 4);                             // int cell count / fill
+  L.o_cell = o;  o = align16(o + total * 4);                             // int cell id of every point
+  L.o_syz = o;   o = align16(o + total * 16);                            // double2 (y,z) sorted by cell
+  L.o_sidx = o;  o = align16(o + total * 4);                             // int original index (within the case), sorted
+  L.bytes = o;
+  return L;
+}
+
+// per-case bases inside the cell arrays: cap_i = max(64, N_i) <= 64 + N_i, so 64*cs + offs[cs] never overlaps
+__device__ __forceinline__ int64_t cell_base(int cs, int64_t beg) { return 64 * (int64_t)cs + beg; }
+
+__global__ __launch_bounds__(256) void resample_init_kernel(unsigned long long *__restrict__ sacc,
+                                                           int *__restrict__ scnt,
+                                                           unsigned long long *__restrict__ bbox, int ncase, int S) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nacc = (int64_t)ncase * 4 * S;
+  if (i < nacc) {
+    const int which = (int)((i / S) & 3);                 // 0, 2: minima; 1, 3: maxima
+    sacc[i] = enc((which & 1) ? -dinf() : dinf());
+    scnt[i] = 0;
   }
-  __shared__ double r[4][256];
-  __shared__ int rc[2][256];
-  r[0][threadIdx.x] = mn1; r[1][threadIdx.x] = mx1; r[2][threadIdx.x] = mn2; r[3][threadIdx.x] = mx2;
-  rc[0][threadIdx.x] = c1; rc[1][threadIdx.x] = c2;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (threadIdx.x < w) {
-      r[0][threadIdx.x] = fmin(r[0][threadIdx.x], r[0][threadIdx.x + w]);
-      r[1][threadIdx.x] = fmax(r[1][threadIdx.x], r[1][threadIdx.x + w]);
-      r[2][threadIdx.x] = fmin(r[2][threadIdx.x], r[2][threadIdx.x + w]);
-      r[3][threadIdx.x] = fmax(r[3][threadIdx.x], r[3][threadIdx.x + w]);
-      rc[0][threadIdx.x] += rc[0][threadIdx.x + w];
-      rc[1][threadIdx.x] += rc[1][threadIdx.x + w];
+  if (i < (int64_t)ncase * 4) bbox[i] = enc((i & 1) ? -dinf() : dinf());
+}
+
+// case of global point index g: the last cs with offs[cs] <= g
+__device__ __forceinline__ int case_of(const int64_t *__restrict__ offs, int ncase, int64_t g) {
+  int lo = 0, hi = ncase;   // invariant: offs[lo] <= g < offs[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (offs[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// one thread per point: bounding box of its case, slice min/max
+__global__ __launch_bounds__(256) void points_pass_kernel(const double *__restrict__ pts, const int64_t *__restrict__ offs,
+                                                         int ncase, int64_t total, const double *__restrict__ zs, int S,
+                                                         double tol1, double tol2,
+                                                         unsigned long long *__restrict__ sacc, int *__restrict__ scnt,
+                                                         unsigned long long *__restrict__ bbox) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = g < total;
+  int cs = -1;
+  double y = 0.0, z = 0.0;
+  if (live) {
+    cs = case_of(offs, ncase, g);
+    y = pts[g * 5 + 1];
+    z = pts[g * 5 + 2];
+  }
+  // ---- bounding box (finite coordinates only): one atomic per wave when the whole wave is in one case
+  const bool fin = live && (y - y == 0.0) && (z - z == 0.0);
+  double ymn = fin ? y : dinf(), ymx = fin ? y : -dinf(), zmn = fin ? z : dinf(), zmx = fin ? z : -dinf();
+  const int cs0 = __shfl(cs, 0);
+  const bool uniform = __all(cs == cs0);
+  if (uniform) {
+    if (cs0 >= 0) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ymn = fmin(ymn, __shfl_xor(ymn, o)); ymx = fmax(ymx, __shfl_xor(ymx, o));
+        zmn = fmin(zmn, __shfl_xor(zmn, o)); zmx = fmax(zmx, __shfl_xor(zmx, o));
+      }
+      if ((threadIdx.x & 63) == 0) {
+        unsigned long long *b = bbox + (int64_t)cs0 * 4;
+        atomicMin(b + 0, enc(ymn)); atomicMax(b + 1, enc(ymx));
+        atomicMin(b + 2, enc(zmn)); atomicMax(b + 3, enc(zmx));
+      }
     }
-    __syncthreads();
+  } else if (fin) {
+    unsigned long long *b = bbox + (int64_t)cs * 4;
+    atomicMin(b + 0, enc(y)); atomicMax(b + 1, enc(y));
+    atomicMin(b + 2, enc(z)); atomicMax(b + 3, enc(z));
   }
-  if (threadIdx.x == 0) {
-    double *w = ws + cs * ws_stride;
-    double lo, hi;
-    if (rc[0][0] > 0) { lo = r[0][0]; hi = r[1][0]; }
-    else if (rc[1][0] > 0) { lo = r[2][0]; hi = r[3][0]; }
-    else { lo = dnan(); hi = dnan(); }
-    w[s] = lo;
-    w[S + s] = hi;
+  if (!live || !(z - z == 0.0)) return;     // |NaN - zv| < tol is false for every slice
+  // ---- slices this point is near (:190-199): candidates from a window twice the tolerance wide, exact test inside
+  const double wlo = z - 2.0 * tol2, whi = z + 2.0 * tol2;
+  int lo = 0, hi = S;                       // first slice with zs >= wlo (zs ascending)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (zs[mid] < wlo) lo = mid + 1; else hi = mid;
+  }
+  unsigned long long *a = sacc + (int64_t)cs * 4 * S;
+  int *c = scnt + (int64_t)cs * 4 * S;
+  const bool ynan = y != y;
+  for (int s = lo; s < S && zs[s] <= whi; ++s) {
+    const double d = fabs(z - zs[s]);
+    if (d < tol1) {
+      if (ynan) atomicAdd(c + 2 * S + s, 1);
+      else { atomicMin(a + 0 * S + s, enc(y)); atomicMax(a + 1 * S + s, enc(y)); }
+      atomicAdd(c + 0 * S + s, 1);
+    }
+    if (d < tol2) {
+      if (ynan) atomicAdd(c + 3 * S + s, 1);
+      else { atomicMin(a + 2 * S + s, enc(y)); atomicMax(a + 3 * S + s, enc(y)); }
+      atomicAdd(c + 1 * S + s, 1);
+    }
   }
 }
 
@@ -90,105 +190,349 @@ __device__ double np_interp(double x, const double *xp, const double *fp, int n)
   return res;
 }
 
-// one block per case: compact the valid slices, interpolate both walls to the W pixel columns
-__global__ __launch_bounds__(256) void wall_interp_kernel(const double *__restrict__ zs, int S,
-                                                         const double *__restrict__ zf, int W,
-                                                         double *__restrict__ ws, int64_t ws_stride) {
+// one block per case: slice results -> wall block, interpolate both walls to the W pixel columns, choose the cell grid
+__global__ __launch_bounds__(256) void case_setup_kernel(const int64_t *__restrict__ offs, const double *__restrict__ zs,
+                                                        int S, const double *__restrict__ zf, int W,
+                                                        const unsigned long long *__restrict__ sacc,
+                                                        const int *__restrict__ scnt,
+                                                        const unsigned long long *__restrict__ bbox,
+                                                        double *__restrict__ wall, int64_t wall_stride,
+                                                        double *__restrict__ grid, double *__restrict__ bnd) {
   extern __shared__ double sm[];  // [3][S]: xp, lo, hi
   double *xp = sm, *lo = sm + S, *hi = sm + 2 * S;
   __shared__ int nvalid;
-  double *w = ws + blockIdx.x * ws_stride;
+  __shared__ int g_ny, g_nz;
+  __shared__ double g_y0, g_z0, g_hy, g_hz;
+  const int cs = blockIdx.x;
+  double *w = wall + (int64_t)cs * wall_stride;
+  const unsigned long long *a = sacc + (int64_t)cs * 4 * S;
+  const int *c = scnt + (int64_t)cs * 4 * S;
+  for (int s = threadIdx.x; s < S; s += 256) {
+    double l, h;
+    if (c[0 * S + s] > 0) {                                     // some point within tol1 (:192-195)
+      if (c[2 * S + s] > 0) { l = dnan(); h = dnan(); }         // np.min / np.max propagate a NaN
+      else { l = dec(a[0 * S + s]); h = dec(a[1 * S + s]); }
+    } else if (c[1 * S + s] > 0) {                              // else within tol2 (:197-199)
+      if (c[3 * S + s] > 0) { l = dnan(); h = dnan(); }
+      else { l = dec(a[2 * S + s]); h = dec(a[3 * S + s]); }
+    } else { l = dnan(); h = dnan(); }
+    w[s] = l;
+    w[S + s] = h;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     int n = 0;
     for (int s = 0; s < S; ++s) {
-      const double a = w[s], b = w[S + s];
-      if (a == a && b == b) { xp[n] = zs[s]; lo[n] = a; hi[n] = b; ++n; }
+      const double l = w[s], h = w[S + s];
+      if (l == l && h == h) { xp[n] = zs[s]; lo[n] = l; hi[n] = h; ++n; }
     }
     nvalid = n;
     *(int *)(w + 2 * S + 2 * W) = n;  // status word: number of valid slices (0 -> numpy would raise)
+    // ---- cell grid: ~2 points per cell, cells square in metres, at most cap = max(64, N) cells
+    const int64_t beg = offs[cs], N = offs[cs + 1] - beg;
+    const double ymn = dec(bbox[cs * 4 + 0]), ymx = dec(bbox[cs * 4 + 1]);
+    const double zmn = dec(bbox[cs * 4 + 2]), zmx = dec(bbox[cs * 4 + 3]);
+    const bool any = ymn <= ymx && zmn <= zmx;
+    const double ry = any ? ymx - ymn : 0.0, rz = any ? zmx - zmn : 0.0;
+    const int64_t cap = N > 64 ? N : 64;
+    const double target = (double)(N / 2 > 1 ? N / 2 : 1);
+    int64_t ny = 1, nz = 1;
+    if (ry > 0.0 && rz > 0.0) {
+      const double h = sqrt(ry * rz / target);
+      const double fy = floor(ry / h) + 1.0, fz = floor(rz / h) + 1.0;
+      ny = fy < (double)cap ? (int64_t)fy : cap;
+      nz = fz < (double)cap ? (int64_t)fz : cap;
+    } else if (ry > 0.0) {
+      ny = (int64_t)target < cap ? (int64_t)target : cap;
+    } else if (rz > 0.0) {
+      nz = (int64_t)target < cap ? (int64_t)target : cap;
+    }
+    while (ny * nz > cap) { if (ny >= nz) ny = (ny + 1) / 2; else nz = (nz + 1) / 2; }
+    g_ny = (int)ny; g_nz = (int)nz;
+    g_y0 = any ? ymn : 0.0; g_z0 = any ? zmn : 0.0;
+    g_hy = ry > 0.0 ? ry / (double)ny : 1.0;
+    g_hz = rz > 0.0 ? rz / (double)nz : 1.0;
+    double *gp = grid + (int64_t)cs * 8;
+    gp[0] = (double)ny; gp[1] = (double)nz; gp[2] = g_y0; gp[3] = g_z0; gp[4] = 1.0 / g_hy; gp[5] = 1.0 / g_hz;
   }
   __syncthreads();
   const int n = nvalid;
   for (int j = threadIdx.x; j < W; j += 256) {
-    double a = dnan(), b = dnan();
-    if (n > 0) { a = np_interp(zf[j], xp, lo, n); b = np_interp(zf[j], xp, hi, n); }
-    w[2 * S + j] = a;
-    w[2 * S + W + j] = b;
+    double l = dnan(), h = dnan();
+    if (n > 0) { l = np_interp(zf[j], xp, lo, n); h = np_interp(zf[j], xp, hi, n); }
+    w[2 * S + j] = l;
+    w[2 * S + W + j] = h;
   }
+  // cell boundaries: by[k] = y0 + k*hy (k = 0..ny), bz[k] likewise; only their ORDER matters for correctness
+  const int64_t beg = offs[cs];
+  double *by = bnd + cell_base(cs, beg) + 3 * (int64_t)cs, *bz = by + g_ny + 1;
+  for (int k = threadIdx.x; k <= g_ny; k += 256) by[k] = g_y0 + (double)k * g_hy;
+  for (int k = threadIdx.x; k <= g_nz; k += 256) bz[k] = g_z0 + (double)k * g_hz;
 }
 
-// one thread per pixel; points staged through LDS in tiles
+// cell of coordinate v along one axis: cell k holds b[k] <= v < b[k+1]; cells 0 and n-1 are open-ended.
+// The guess only saves steps; the two loops make the result agree with the boundary table exactly, which is what
+// the search's stop test relies on.  NaN -> cell 0.
+__device__ __forceinline__ int bin1(double v, double o, double inv, const double *__restrict__ b, int n) {
+  const double t = (v - o) * inv;
+  int k = (t >= 0.0) ? (t < (double)(n - 1) ? (int)t : n - 1) : 0;
+  while (k + 1 < n && v >= b[k + 1]) ++k;
+  while (k > 0 && v < b[k]) --k;
+  return k;
+}
+
+struct CaseGrid {
+  int ny, nz;
+  double y0, z0, invy, invz;
+  const double *by, *bz;
+};
+__device__ __forceinline__ CaseGrid load_grid(const double *__restrict__ grid, const double *__restrict__ bnd, int cs,
+                                              int64_t beg) {
+  const double *gp = grid + (int64_t)cs * 8;
+  CaseGrid G;
+  G.ny = (int)gp[0]; G.nz = (int)gp[1]; G.y0 = gp[2]; G.z0 = gp[3]; G.invy = gp[4]; G.invz = gp[5];
+  G.by = bnd + cell_base(cs, beg) + 3 * (int64_t)cs;
+  G.bz = G.by + G.ny + 1;
+  return G;
+}
+
+__global__ __launch_bounds__(256) void bin_count_kernel(const double *__restrict__ pts, const int64_t *__restrict__ offs,
+                                                       int ncase, int64_t total, const double *__restrict__ grid,
+                                                       const double *__restrict__ bnd, int *__restrict__ cnt,
+                                                       int *__restrict__ cell) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total) return;
+  const int cs = case_of(offs, ncase, g);
+  const int64_t beg = offs[cs];
+  const CaseGrid G = load_grid(grid, bnd, cs, beg);
+  const int cy = bin1(pts[g * 5 + 1], G.y0, G.invy, G.by, G.ny);
+  const int cz = bin1(pts[g * 5 + 2], G.z0, G.invz, G.bz, G.nz);
+  const int c = cy * G.nz + cz;
+  cell[g] = c;
+  atomicAdd(cnt + cell_base(cs, beg) + c, 1);
+}
+
+// one block per case: exclusive scan of the cell counts -> cell_start[0..ncell]; counts reset to 0 (scatter's fill)
+__global__ __launch_bounds__(256) void bin_scan_kernel(const int64_t *__restrict__ offs, const double *__restrict__ grid,
+                                                      int *__restrict__ cnt, int *__restrict__ start) {
+  __shared__ int part[256];
+  const int cs = blockIdx.x, tid = threadIdx.x;
+  const int64_t beg = offs[cs];
+  const double *gp = grid + (int64_t)cs * 8;
+  const int ncell = (int)gp[0] * (int)gp[1];
+  int *c = cnt + cell_base(cs, beg);
+  int *st = start + cell_base(cs, beg) + cs;
+  const int per = (ncell + 255) / 256;
+  const int a = tid * per, b = (a + per < ncell) ? a + per : ncell;
+  int sum = 0;
+  for (int i = a; i < b; ++i) sum += c[i];
+  part[tid] = sum;
+  __syncthreads();
+  // Hillis-Steele inclusive scan of the 256 partials
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = (tid >= o) ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - sum;   // exclusive prefix of this thread's segment
+  for (int i = a; i < b; ++i) {
+    const int v = c[i];
+    st[i] = run;
+    run += v;
+    c[i] = 0;
+  }
+  if (tid == 255) st[ncell] = part[255];
+}
+
+__global__ __launch_bounds__(256) void bin_scatter_kernel(const double *__restrict__ pts, const int64_t *__restrict__ offs,
+                                                         int ncase, int64_t total, const int *__restrict__ cell,
+                                                         const int *__restrict__ start, int *__restrict__ cnt,
+                                                         double2 *__restrict__ syz, int *__restrict__ sidx) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total) return;
+  const int cs = case_of(offs, ncase, g);
+  const int64_t beg = offs[cs];
+  const int c = cell[g];
+  const int pos = start[cell_base(cs, beg) + cs + c] + atomicAdd(cnt + cell_base(cs, beg) + c, 1);
+  syz[beg + pos] = make_double2(pts[g * 5 + 1], pts[g * 5 + 2]);
+  sidx[beg + pos] = (int)(g - beg);
+}
+
+constexpr int TILE_H = 8, TILE_W = 32;   // pixels per block: 8 rows x 32 columns (one wave = 2 rows)
+
 __global__ __launch_bounds__(256) void nearest_kernel(const double *__restrict__ pts, const int64_t *__restrict__ offs,
-                                                     const double *__restrict__ yf, int H,
+                                                     int ncase, const double *__restrict__ yf, int H,
                                                      const double *__restrict__ zf, int W, int S,
-                                                     const double *__restrict__ ws, int64_t ws_stride,
-                                                     double p_convert, double *__restrict__ out) {
-  constexpr int TILE = 1024;
-  __shared__ double2 tile[TILE];
-  const int cs = blockIdx.y;
-  const int64_t beg = offs[cs], end = offs[cs + 1];
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  const bool live = pix < H * W;
-  const int i = live ? pix / W : 0, j = live ? pix - i * W : 0;
-  const double qy = yf[i], qz = zf[j];
-  double best = __longlong_as_double(0x7ff0000000000000LL);
-  int64_t besti = -1;
-  for (int64_t t0 = beg; t0 < end; t0 += TILE) {
-    const int cnt = (int)((end - t0) < TILE ? (end - t0) : TILE);
-    __syncthreads();
-    for (int k = threadIdx.x; k < cnt; k += 256) {
-      const double *p = pts + (t0 + k) * 5;
-      tile[k] = make_double2(p[1], p[2]);
-    }
-    __syncthreads();
-    for (int k = 0; k < cnt; ++k) {
-      const double2 s = tile[k];
-      const double dy = s.x - qy, dz = s.y - qz;
-      const double d = dy * dy + dz * dz;   // two products, one sum, each rounded (contraction is off)
-      if (d < best) { best = d; besti = t0 + k; }   // strict: the lowest index wins ties
+                                                     const double *__restrict__ wall, int64_t wall_stride,
+                                                     const double *__restrict__ grid, const double *__restrict__ bnd,
+                                                     const int *__restrict__ start, const double2 *__restrict__ syz,
+                                                     const int *__restrict__ sidx, double p_convert,
+                                                     double *__restrict__ out) {
+  __shared__ double stage[TILE_H * TILE_W * 5];
+  const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+  const int tiles = tiles_x * tiles_y;
+  // XCD-aware order: blocks L, L+8, L+16, ... share an XCD (round-robin dispatch), so give each XCD whole cases --
+  // its L2 then holds the sorted points and cell lists of the cases it works on and no other XCD re-reads them
+  const int64_t L = blockIdx.x;
+  const int ncase8 = ncase & ~7;
+  int cs, tile;
+  if (L < (int64_t)ncase8 * tiles) {
+    const int xcd = (int)(L & 7);
+    const int64_t j = L >> 3;
+    cs = (int)(j / tiles) * 8 + xcd;
+    tile = (int)(j % tiles);
+  } else {
+    cs = (int)(L / tiles);
+    tile = (int)(L % tiles);
+  }
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int tid = threadIdx.x;
+  const int i = ty * TILE_H + (tid >> 5), j = tx * TILE_W + (tid & 31);
+  const bool live = i < H && j < W;
+  const int64_t beg = offs[cs];
+  const CaseGrid G = load_grid(grid, bnd, cs, beg);
+  const int *st = start + cell_base(cs, beg) + cs;
+  const double2 *sp = syz + beg;
+  const int *si = sidx + beg;
+  const double qy = yf[live ? i : 0], qz = zf[live ? j : 0];
+  double best = dinf();
+  int besti = 0x7fffffff;
+  if (live) {
+    const int cqy = bin1(qy, G.y0, G.invy, G.by, G.ny), cqz = bin1(qz, G.z0, G.invz, G.bz, G.nz);
+    for (int r = 1;; ++r) {
+      const int y0 = cqy - r > 0 ? cqy - r : 0, y1 = cqy + r < G.ny - 1 ? cqy + r : G.ny - 1;
+      const int z0 = cqz - r > 0 ? cqz - r : 0, z1 = cqz + r < G.nz - 1 ? cqz + r : G.nz - 1;
+      for (int cy = y0; cy <= y1; ++cy) {
+        const bool full = r == 1 || cy == cqy - r || cy == cqy + r;
+        // full row of the box: cells (cy, z0..z1) are consecutive in the sorted order.  Middle rows of ring r >= 2:
+        // only the two end cells (cy, cqz - r) and (cy, cqz + r) are new.
+        for (int part = 0; part < 2; ++part) {
+          int ca, cb;
+          if (full) {
+            if (part) break;
+            ca = cy * G.nz + z0; cb = cy * G.nz + z1 + 1;
+          } else {
+            const int cz = part ? cqz + r : cqz - r;
+            if (cz < 0 || cz > G.nz - 1) continue;
+            ca = cy * G.nz + cz; cb = ca + 1;
+          }
+          const int pa = st[ca], pb = st[cb];
+          for (int k = pa; k < pb; ++k) {
+            const double2 s = sp[k];
+            const int id = si[k];
+            const double dy = s.x - qy, dz = s.y - qz;
+            const double d = dy * dy + dz * dz;   // two products, one sum, each rounded (contraction is off)
+            if (d < best || (d == best && id < besti)) { best = d; besti = id; }   // ties: the lowest index
+          }
+        }
+      }
+      if (y0 == 0 && y1 == G.ny - 1 && z0 == 0 && z1 == G.nz - 1) break;    // every cell visited
+      // smallest rounded distance any point outside the box can have (see the header): stop only STRICTLY below it
+      double B = dinf();
+      if (y1 < G.ny - 1) { const double t = G.by[y1 + 1] - qy; B = fmin(B, t * t); }
+      if (y0 > 0)        { const double t = G.by[y0] - qy;     B = fmin(B, t * t); }
+      if (z1 < G.nz - 1) { const double t = G.bz[z1 + 1] - qz; B = fmin(B, t * t); }
+      if (z0 > 0)        { const double t = G.bz[z0] - qz;     B = fmin(B, t * t); }
+      if (best < B) break;
     }
   }
-  if (!live) return;
-  const double *w = ws + cs * ws_stride;
-  const double ylo = w[2 * S + j], yhi = w[2 * S + W + j];
   double P = 0.0, U = 0.0;
-  if (besti >= 0) {
-    P = pts[besti * 5 + 3];
-    U = pts[besti * 5 + 4];
-    if (P < 0.0) P = 0.0;                      // :182
+  if (live) {
+    const double *w = wall + (int64_t)cs * wall_stride;
+    const double ylo = w[2 * S + j], yhi = w[2 * S + W + j];
+    if (besti != 0x7fffffff) {
+      P = pts[(beg + besti) * 5 + 3];
+      U = pts[(beg + besti) * 5 + 4];
+      if (P < 0.0) P = 0.0;                      // :182
+    }
+    if (qy < ylo || qy > yhi) { P = 0.0; U = 0.0; }  // :220-221 (comparisons with NaN are false, as in numpy)
   }
-  if (qy < ylo || qy > yhi) { P = 0.0; U = 0.0; }  // :220-221 (comparisons with NaN are false, as in numpy)
-  double *o = out + ((int64_t)cs * H * W + pix) * 5;
-  o[0] = qy; o[1] = qz; o[2] = P; o[3] = U; o[4] = P * p_convert;
+  double *s5 = stage + tid * 5;
+  s5[0] = qy; s5[1] = qz; s5[2] = P; s5[3] = U; s5[4] = P * p_convert;
+  __syncthreads();
+  // a tile row = up to 32 pixels x 5 columns = 160 consecutive doubles of the output table
+  const int cols = (W - tx * TILE_W) < TILE_W ? (W - tx * TILE_W) : TILE_W;
+  for (int e = tid; e < TILE_H * TILE_W * 5; e += 256) {
+    const int r = e / (TILE_W * 5), k = e - r * (TILE_W * 5);
+    const int row = ty * TILE_H + r;
+    if (row < H && k < cols * 5)
+      out[(((int64_t)cs * H + row) * W + tx * TILE_W) * 5 + k] = stage[e];
+  }
 }
 
 }  // namespace cfd
 
 using namespace cfd;
 
-static inline int64_t ws_stride_doubles(int W, int S) { return 2 * (int64_t)S + 2 * (int64_t)W + 2; }
-
-extern "C" int64_t cfd_resample_workspace_bytes(int ncase, int W, int S) {
-  return (int64_t)ncase * ws_stride_doubles(W, S) * 8;
+extern "C" int64_t cfd_resample_workspace_bytes(int ncase, int W, int S, int64_t total_points) {
+  if (ncase <= 0 || W <= 0 || S <= 0 || total_points < 0) return -1;
+  return rs_layout(ncase, W, S, total_points).bytes;
 }
 
-extern "C" int cfd_resample_nearest(const double *pts, const int64_t *case_offsets, int ncase, const double *y_final,
-                                    int H, const double *z_final, int W, const double *z_samples, int S, double tol1,
-                                    double tol2, double p_convert, double *out, void *workspace, void *stream) {
+namespace cfd {
+// shared by cfd_resample_nearest and its no-allocation variant
+int resample_launch(const double *pts, const int64_t *case_offsets, int ncase, int64_t total, const double *y_final,
+                    int H, const double *z_final, int W, const double *z_samples, int S, double tol1, double tol2,
+                    double p_convert, double *out, void *workspace, hipStream_t st) {
   CFD_REQUIRE(pts && case_offsets && y_final && z_final && z_samples && out && workspace, "NULL pointer");
   CFD_REQUIRE(ncase > 0 && H > 0 && W > 0 && S > 0 && S <= 2048, "bad sizes ncase=%d H=%d W=%d S=%d", ncase, H, W, S);
   CFD_REQUIRE((int64_t)H * W < (1LL << 31), "grid too large");
-  hipStream_t st = (hipStream_t)stream;
-  double *ws = (double *)workspace;
-  const int64_t stride = ws_stride_doubles(W, S);
-  hipLaunchKernelGGL(wall_slices_kernel, dim3(S, ncase), dim3(256), 0, st, pts, case_offsets, z_samples, S, tol1, tol2,
-                     ws, stride);
+  CFD_REQUIRE(total >= 0 && total < (1LL << 31), "total_points %lld out of range", (long long)total);
+  CFD_REQUIRE(tol1 >= 0.0 && tol2 >= 0.0, "negative tolerance");
+  const RsLayout L = rs_layout(ncase, W, S, total);
+  char *base = (char *)workspace;
+  double *wall = (double *)(base + L.o_wall);
+  unsigned long long *sacc = (unsigned long long *)(base + L.o_sacc);
+  int *scnt = (int *)(base + L.o_scnt);
+  unsigned long long *bbox = (unsigned long long *)(base + L.o_bbox);
+  double *grid = (double *)(base + L.o_grid);
+  double *bnd = (double *)(base + L.o_bnd);
+  int *start = (int *)(base + L.o_start);
+  int *cnt = (int *)(base + L.o_cnt);
+  int *cell = (int *)(base + L.o_cell);
+  double2 *syz = (double2 *)(base + L.o_syz);
+  int *sidx = (int *)(base + L.o_sidx);
+  const int64_t ninit = (int64_t)ncase * 4 * S;
+  hipLaunchKernelGGL(resample_init_kernel, dim3(cdiv(ninit, 256)), dim3(256), 0, st, sacc, scnt, bbox, ncase, S);
   CFD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wall_interp_kernel, dim3(ncase), dim3(256), 3 * S * sizeof(double), st, z_samples, S, z_final, W,
-                     ws, stride);
+  CFD_HIP(hipMemsetAsync(cnt, 0, (size_t)(L.o_cell - L.o_cnt), st));
+  const int pblocks = cdiv(total, 256);
+  if (pblocks > 0) {
+    hipLaunchKernelGGL(points_pass_kernel, dim3(pblocks), dim3(256), 0, st, pts, case_offsets, ncase, total, z_samples,
+                       S, tol1, tol2, sacc, scnt, bbox);
+    CFD_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(case_setup_kernel, dim3(ncase), dim3(256), 3 * S * sizeof(double), st, case_offsets, z_samples, S,
+                     z_final, W, (const unsigned long long *)sacc, (const int *)scnt, (const unsigned long long *)bbox,
+                     wall, L.wall_stride, grid, bnd);
   CFD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nearest_kernel, dim3((H * W + 255) / 256, ncase), dim3(256), 0, st, pts, case_offsets, y_final, H,
-                     z_final, W, S, (const double *)ws, stride, p_convert, out);
+  if (pblocks > 0) {
+    hipLaunchKernelGGL(bin_count_kernel, dim3(pblocks), dim3(256), 0, st, pts, case_offsets, ncase, total,
+                       (const double *)grid, (const double *)bnd, cnt, cell);
+    CFD_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(bin_scan_kernel, dim3(ncase), dim3(256), 0, st, case_offsets, (const double *)grid, cnt, start);
+  CFD_LAUNCH_CHECK();
+  if (pblocks > 0) {
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(pblocks), dim3(256), 0, st, pts, case_offsets, ncase, total,
+                       (const int *)cell, (const int *)start, cnt, syz, sidx);
+    CFD_LAUNCH_CHECK();
+  }
+  const int64_t tiles = (int64_t)cdiv(W, TILE_W) * cdiv(H, TILE_H);
+  CFD_REQUIRE(tiles * ncase < (1LL << 31), "too many tiles in one call");
+  hipLaunchKernelGGL(nearest_kernel, dim3((unsigned)(tiles * ncase)), dim3(256), 0, st, pts, case_offsets, ncase, y_final,
+                     H, z_final, W, S, (const double *)wall, L.wall_stride, (const double *)grid, (const double *)bnd,
+                     (const int *)start, (const double2 *)syz, (const int *)sidx, p_convert, out);
   CFD_LAUNCH_CHECK();
   return CFD_OK;
+}
+}  // namespace cfd
+
+extern "C" int cfd_resample_nearest(const double *pts, const int64_t *case_offsets, int ncase, int64_t total_points,
+                                    const double *y_final, int H, const double *z_final, int W,
+                                    const double *z_samples, int S, double tol1, double tol2, double p_convert,
+                                    double *out, void *workspace, void *stream) {
+  return resample_launch(pts, case_offsets, ncase, total_points, y_final, H, z_final, W, z_samples, S, tol1, tol2,
+                         p_convert, out, workspace, (hipStream_t)stream);
 }

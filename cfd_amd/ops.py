@@ -389,13 +389,16 @@ class ResampleJob:
         d = lambda a: torch.from_numpy(a).to(device)
         self.offs, self.yf, self.zf, self.zs = d(offs), d(y_final), d(z_final), d(z_samples)
         self.out = torch.empty((self.ncase, height * width, 5), dtype=torch.float64, device=device)
-        wsb = lib.cfd_resample_workspace_bytes(self.ncase, width, N_SLICES)
-        self.ws = torch.empty(wsb // 8, dtype=torch.float64, device=device)
+        wsb = lib.cfd_resample_workspace_bytes(self.ncase, width, N_SLICES, self.n_points)
+        if wsb < 0:
+            check(-1, "cfd_resample_workspace_bytes")
+        self.ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=device)
 
     def run(self) -> torch.Tensor:
-        check(_lib.load().cfd_resample_nearest(_ptr(self.pts), _ptr(self.offs), self.ncase, _ptr(self.yf), self.H,
-                                               _ptr(self.zf), self.W, _ptr(self.zs), N_SLICES, TOL_1, TOL_2, P_CONVERT,
-                                               _ptr(self.out), _ptr(self.ws), _stream()), "cfd_resample_nearest")
+        check(_lib.load().cfd_resample_nearest(_ptr(self.pts), _ptr(self.offs), self.ncase, self.n_points, _ptr(self.yf),
+                                               self.H, _ptr(self.zf), self.W, _ptr(self.zs), N_SLICES, TOL_1, TOL_2,
+                                               P_CONVERT, _ptr(self.out), _ptr(self.ws), _stream()),
+              "cfd_resample_nearest")
         return self.out
 
     def algorithmic_bytes(self) -> int:
@@ -404,7 +407,7 @@ class ResampleJob:
 
     def n_valid_slices(self) -> np.ndarray:
         stride = 2 * N_SLICES + 2 * self.W + 2
-        col = self.ws.view(self.ncase, stride)[:, 2 * N_SLICES + 2 * self.W]
+        col = self.ws[:self.ncase * stride].view(self.ncase, stride)[:, 2 * N_SLICES + 2 * self.W]
         return np.ascontiguousarray(col.cpu().numpy()).view(np.int32)[::2]
 
 

@@ -68,7 +68,7 @@ def nearest_index(Y_all, Z_all, y_final, z_final, chunk: int = 2048, return_ties
     return (out, ties) if return_ties else out
 
 
-def resample(arr: np.ndarray, height: int = 64, width: int = 512, return_ties: bool = False):
+def resample(arr: np.ndarray, height: int = 64, width: int = 512, return_ties: bool = False, chunk: int = 2048):
     """arr: (N,5) fp64 rows x,y,z,p,Umean  ->  (H*W,5) fp64 rows
     y_center,z_center,p_center,Umean_center,p_convert (the reference's output CSV)."""
     arr = np.array(arr, dtype=np.float64, copy=True)
@@ -78,7 +78,7 @@ def resample(arr: np.ndarray, height: int = 64, width: int = 512, return_ties: b
     P_all[P_all < 0] = 0                                     # :182
     U_all = arr[:, 4]
     y_lo, y_hi = wall_bounds(Y_all, Z_all, z_final)
-    res = nearest_index(Y_all, Z_all, y_final, z_final, return_ties=return_ties)
+    res = nearest_index(Y_all, Z_all, y_final, z_final, chunk=chunk, return_ties=return_ties)
     idx, ties = res if return_ties else (res, None)
     P = P_all[idx].reshape(height, width)
     U = U_all[idx].reshape(height, width)

@@ -340,6 +340,72 @@ def test_resample_batched_ragged():
         assert np.array_equal(o.view(np.uint64), OR.resample(c, 32, 128).view(np.uint64))
 
 
+def _wall_points(rng, n):
+    """n scattered points in the channel box, a few of them snapped onto slice positions so that the wall exists"""
+    pts = np.zeros((n, 5))
+    pts[:, 1] = rng.uniform(-2e-3, 2e-3, n)
+    pts[:, 2] = rng.uniform(0, 50e-3, n)
+    pts[:, 3] = rng.normal(size=n)
+    pts[:, 4] = rng.random(n)
+    k = min(n, 303)
+    pts[:k, 2] = np.linspace(0, 50e-3, 101)[np.arange(k) % 101]
+    return pts
+
+
+@pytest.mark.parametrize("name", ["clustered", "duplicates", "line_y", "line_z", "single", "lattice_ties", "outside_box"])
+def test_resample_cell_search_adversarial(name):
+    """the cell-grid ring search must return the argmin of the full scan (lowest index on ties) whatever the point
+    layout: dense clusters with empty space around them, exact duplicates (equal distance, different index), points on
+    one line (degenerate bounding box), a single point, a lattice that ties with pixel centres, queries outside the
+    points' bounding box.  Bit-exact against the brute-force oracle."""
+    from cfd_amd import ops
+    rng = np.random.default_rng(7)
+    H, W = 13, 37                                     # ragged tiles too
+    if name == "clustered":
+        pts = _wall_points(rng, 3000)
+        pts[400:, 1] = 1.5e-3 + 1e-5 * rng.normal(size=2600)
+        pts[400:, 2] = 40e-3 + 1e-4 * rng.normal(size=2600)
+    elif name == "duplicates":
+        pts = _wall_points(rng, 600)
+        pts = np.concatenate([pts, pts[::-1]])         # every location twice, the copies in reverse order
+        pts[600:, 3:] = rng.random((600, 2))           # ... with different values: the index decides
+    elif name == "line_y":
+        pts = _wall_points(rng, 500)
+        pts[:, 1] = 3e-4
+    elif name == "line_z":
+        pts = _wall_points(rng, 500)
+        pts[:, 2] = 25e-3
+    elif name == "single":
+        pts = np.array([[0.0, 1e-4, 25e-3, 2.0, 3.0]])
+    elif name == "lattice_ties":
+        yy, zz = np.meshgrid(-2e-3 + np.arange(14) * (4e-3 / 13), np.arange(38) * (50e-3 / 37), indexing="ij")
+        pts = np.zeros((yy.size, 5))                   # lattice nodes = pixel corners: four-way ties everywhere
+        pts[:, 1], pts[:, 2] = yy.ravel(), zz.ravel()
+        pts[:, 3], pts[:, 4] = rng.random(yy.size), rng.random(yy.size)
+    else:
+        pts = _wall_points(rng, 800)
+        pts[:, 1] = pts[:, 1] * 0.1                    # the points fill a thin band; most pixels lie outside their box
+        pts[:, 2] = 20e-3 + pts[:, 2] * 0.1
+    out = ops.resample_nearest([pts, pts[: max(1, len(pts) // 2)]], H, W)
+    for o, c in zip(out, (pts, pts[: max(1, len(pts) // 2)])):
+        try:
+            ref = OR.resample(c, H, W)
+        except ValueError:                             # np.interp on an empty wall: the half case of "single" etc.
+            continue
+        assert np.array_equal(o.view(np.uint64), ref.view(np.uint64))
+
+
+def test_resample_openfoam_scale_points():
+    """100 000 source points in one case (an OpenFOAM mesh, not the 2 121-point probe grid) next to a small case in the
+    same launch; oracle brute force in small query chunks"""
+    from cfd_amd import ops
+    rng = np.random.default_rng(11)
+    big, small = _wall_points(rng, 100_000), _wall_points(rng, 700)
+    out = ops.resample_nearest([big, small], 32, 128)
+    assert np.array_equal(out[0].view(np.uint64), OR.resample(big, 32, 128, chunk=128).view(np.uint64))
+    assert np.array_equal(out[1].view(np.uint64), OR.resample(small, 32, 128).view(np.uint64))
+
+
 def test_resample_no_slices_raises():
     from cfd_amd import ops
     pts = np.array([[0.0, 0.0, 0.02525, 1.0, 1.0]])  # no point within 1e-4 of any slice
