@@ -104,67 +104,84 @@ __device__ __forceinline__ int case_of(const int64_t *__restrict__ offs, int nca
   return lo;
 }
 
-// one thread per point: bounding box of its case, slice min/max
+// Bounding box of every case and the min/max of y in every z slice a point is near (:190-199).
+// grid = (K, ncase): K blocks share a case (block b takes points b*256 + tid, stride K*256).  All accumulation happens in
+// LDS (64-bit min/max atomics on order-preserving encodings); a block then folds only the entries it touched into the
+// case's global accumulators, so the global atomics per case are O(K * slices touched), not O(points).
+// A point within tol1 of a slice counts for class 1 only, a point in [tol1, tol2) for class 2 only: class 2 is consulted
+// only when no point is within tol1 (:196), and then the two definitions coincide (needs tol1 <= tol2, else both).
 __global__ __launch_bounds__(256) void points_pass_kernel(const double *__restrict__ pts, const int64_t *__restrict__ offs,
-                                                         int ncase, int64_t total, const double *__restrict__ zs, int S,
-                                                         double tol1, double tol2,
+                                                         const double *__restrict__ zs, int S, double tol1, double tol2,
                                                          unsigned long long *__restrict__ sacc, int *__restrict__ scnt,
                                                          unsigned long long *__restrict__ bbox) {
-  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = g < total;
-  int cs = -1;
-  double y = 0.0, z = 0.0;
-  if (live) {
-    cs = case_of(offs, ncase, g);
-    y = pts[g * 5 + 1];
-    z = pts[g * 5 + 2];
-  }
-  // ---- bounding box (finite coordinates only): one atomic per wave when the whole wave is in one case
-  const bool fin = live && (y - y == 0.0) && (z - z == 0.0);
-  double ymn = fin ? y : dinf(), ymx = fin ? y : -dinf(), zmn = fin ? z : dinf(), zmx = fin ? z : -dinf();
-  const int cs0 = __shfl(cs, 0);
-  const bool uniform = __all(cs == cs0);
-  if (uniform) {
-    if (cs0 >= 0) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        ymn = fmin(ymn, __shfl_xor(ymn, o)); ymx = fmax(ymx, __shfl_xor(ymx, o));
-        zmn = fmin(zmn, __shfl_xor(zmn, o)); zmx = fmax(zmx, __shfl_xor(zmx, o));
+  extern __shared__ unsigned long long lacc[];      // [4][S] mn1 mx1 mn2 mx2, then int [2][S] NaN counts, then 4 bbox
+  const int cs = blockIdx.y, tid = threadIdx.x;
+  int *lnan = (int *)(lacc + 4 * S);
+  unsigned long long *lbox = lacc + 4 * S + (2 * S + 1) / 2;
+  for (int s = tid; s < 4 * S; s += 256) lacc[s] = enc(((s / S) & 1) ? -dinf() : dinf());
+  for (int s = tid; s < 2 * S; s += 256) lnan[s] = 0;
+  if (tid < 4) lbox[tid] = enc((tid & 1) ? -dinf() : dinf());
+  __syncthreads();
+  const int64_t beg = offs[cs], end = offs[cs + 1];
+  const bool both = !(tol1 <= tol2);
+  double ymn = dinf(), ymx = -dinf(), zmn = dinf(), zmx = -dinf();
+  for (int64_t g = beg + (int64_t)blockIdx.x * 256 + tid; g < end; g += (int64_t)gridDim.x * 256) {
+    const double y = pts[g * 5 + 1], z = pts[g * 5 + 2];
+    if ((y - y == 0.0) && (z - z == 0.0)) {          // bounding box: finite coordinates only
+      ymn = fmin(ymn, y); ymx = fmax(ymx, y); zmn = fmin(zmn, z); zmx = fmax(zmx, z);
+    }
+    if (!(z - z == 0.0)) continue;                   // |NaN - zv| < tol is false for every slice
+    // candidate slices from a window twice the tolerance wide (zs ascending), the exact test inside
+    const double wlo = z - 2.0 * tol2 - 2.0 * tol1, whi = z + 2.0 * tol2 + 2.0 * tol1;
+    int lo = 0, hi = S;                              // first slice with zs >= wlo
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (zs[mid] < wlo) lo = mid + 1; else hi = mid;
+    }
+    const bool ynan = y != y;
+    for (int s = lo; s < S && zs[s] <= whi; ++s) {
+      const double d = fabs(z - zs[s]);
+      const bool in1 = d < tol1, in2 = d < tol2;
+      if (in1) {
+        if (ynan) atomicAdd(lnan + s, 1);
+        else { atomicMin(lacc + 0 * S + s, enc(y)); atomicMax(lacc + 1 * S + s, enc(y)); }
       }
-      if ((threadIdx.x & 63) == 0) {
-        unsigned long long *b = bbox + (int64_t)cs0 * 4;
-        atomicMin(b + 0, enc(ymn)); atomicMax(b + 1, enc(ymx));
-        atomicMin(b + 2, enc(zmn)); atomicMax(b + 3, enc(zmx));
+      if (in2 && (both || !in1)) {
+        if (ynan) atomicAdd(lnan + S + s, 1);
+        else { atomicMin(lacc + 2 * S + s, enc(y)); atomicMax(lacc + 3 * S + s, enc(y)); }
       }
     }
-  } else if (fin) {
-    unsigned long long *b = bbox + (int64_t)cs * 4;
-    atomicMin(b + 0, enc(y)); atomicMax(b + 1, enc(y));
-    atomicMin(b + 2, enc(z)); atomicMax(b + 3, enc(z));
   }
-  if (!live || !(z - z == 0.0)) return;     // |NaN - zv| < tol is false for every slice
-  // ---- slices this point is near (:190-199): candidates from a window twice the tolerance wide, exact test inside
-  const double wlo = z - 2.0 * tol2, whi = z + 2.0 * tol2;
-  int lo = 0, hi = S;                       // first slice with zs >= wlo (zs ascending)
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (zs[mid] < wlo) lo = mid + 1; else hi = mid;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ymn = fmin(ymn, __shfl_xor(ymn, o)); ymx = fmax(ymx, __shfl_xor(ymx, o));
+    zmn = fmin(zmn, __shfl_xor(zmn, o)); zmx = fmax(zmx, __shfl_xor(zmx, o));
   }
+  if ((tid & 63) == 0) {
+    atomicMin(lbox + 0, enc(ymn)); atomicMax(lbox + 1, enc(ymx));
+    atomicMin(lbox + 2, enc(zmn)); atomicMax(lbox + 3, enc(zmx));
+  }
+  __syncthreads();
+  // fold what this block touched into the case's accumulators
   unsigned long long *a = sacc + (int64_t)cs * 4 * S;
   int *c = scnt + (int64_t)cs * 4 * S;
-  const bool ynan = y != y;
-  for (int s = lo; s < S && zs[s] <= whi; ++s) {
-    const double d = fabs(z - zs[s]);
-    if (d < tol1) {
-      if (ynan) atomicAdd(c + 2 * S + s, 1);
-      else { atomicMin(a + 0 * S + s, enc(y)); atomicMax(a + 1 * S + s, enc(y)); }
-      atomicAdd(c + 0 * S + s, 1);
+  for (int s = tid; s < 2 * S; s += 256) {           // s < S: class 1, else class 2
+    const int k = s < S ? 0 : 2, q = s < S ? s : s - S;
+    const unsigned long long mn = lacc[k * S + q], mx = lacc[(k + 1) * S + q];
+    const int nn = lnan[s];
+    if (mn <= mx) {                                  // at least one finite y landed here
+      atomicMin(a + k * S + q, mn);
+      atomicMax(a + (k + 1) * S + q, mx);
+      atomicAdd(c + (k >> 1) * S + q, 1);            // "some point in this class": > 0 is all that is read
     }
-    if (d < tol2) {
-      if (ynan) atomicAdd(c + 3 * S + s, 1);
-      else { atomicMin(a + 2 * S + s, enc(y)); atomicMax(a + 3 * S + s, enc(y)); }
-      atomicAdd(c + 1 * S + s, 1);
+    if (nn > 0) {
+      atomicAdd(c + (k >> 1) * S + q, 1);
+      atomicAdd(c + (2 + (k >> 1)) * S + q, nn);
     }
+  }
+  if (tid < 4) {
+    if (tid & 1) atomicMax(bbox + (int64_t)cs * 4 + tid, lbox[tid]);
+    else atomicMin(bbox + (int64_t)cs * 4 + tid, lbox[tid]);
   }
 }
 
@@ -197,7 +214,8 @@ __global__ __launch_bounds__(256) void case_setup_kernel(const int64_t *__restri
                                                         const int *__restrict__ scnt,
                                                         const unsigned long long *__restrict__ bbox,
                                                         double *__restrict__ wall, int64_t wall_stride,
-                                                        double *__restrict__ grid, double *__restrict__ bnd) {
+                                                        double *__restrict__ grid, double *__restrict__ bnd,
+                                                        double pts_per_cell) {
   extern __shared__ double sm[];  // [3][S]: xp, lo, hi
   double *xp = sm, *lo = sm + S, *hi = sm + 2 * S;
   __shared__ int nvalid;
@@ -235,7 +253,8 @@ __global__ __launch_bounds__(256) void case_setup_kernel(const int64_t *__restri
     const bool any = ymn <= ymx && zmn <= zmx;
     const double ry = any ? ymx - ymn : 0.0, rz = any ? zmx - zmn : 0.0;
     const int64_t cap = N > 64 ? N : 64;
-    const double target = (double)(N / 2 > 1 ? N / 2 : 1);
+    const double tcells = floor((double)N / pts_per_cell);
+    const double target = tcells > 1.0 ? tcells : 1.0;
     int64_t ny = 1, nz = 1;
     if (ry > 0.0 && rz > 0.0) {
       const double h = sqrt(ry * rz / target);
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(256) void nearest_kernel(const double *__restrict__
   const int *si = sidx + beg;
   const double qy = yf[live ? i : 0], qz = zf[live ? j : 0];
   double best = dinf();
-  int besti = 0x7fffffff;
+  int bestk = -1;            // position in the sorted order; the original index is looked up only on ties and at the end
   if (live) {
     const int cqy = bin1(qy, G.y0, G.invy, G.by, G.ny), cqz = bin1(qz, G.z0, G.invz, G.bz, G.nz);
     for (int r = 1;; ++r) {
@@ -420,10 +439,10 @@ __global__ __launch_bounds__(256) void nearest_kernel(const double *__restrict__
           const int pa = st[ca], pb = st[cb];
           for (int k = pa; k < pb; ++k) {
             const double2 s = sp[k];
-            const int id = si[k];
             const double dy = s.x - qy, dz = s.y - qz;
             const double d = dy * dy + dz * dz;   // two products, one sum, each rounded (contraction is off)
-            if (d < best || (d == best && id < besti)) { best = d; besti = id; }   // ties: the lowest index
+            if (d < best) { best = d; bestk = k; }
+            else if (d == best && bestk >= 0 && si[k] < si[bestk]) bestk = k;   // ties: the lowest original index
           }
         }
       }
@@ -441,7 +460,8 @@ __global__ __launch_bounds__(256) void nearest_kernel(const double *__restrict__
   if (live) {
     const double *w = wall + (int64_t)cs * wall_stride;
     const double ylo = w[2 * S + j], yhi = w[2 * S + W + j];
-    if (besti != 0x7fffffff) {
+    if (bestk >= 0) {
+      const int besti = si[bestk];
       P = pts[(beg + besti) * 5 + 3];
       U = pts[(beg + besti) * 5 + 4];
       if (P < 0.0) P = 0.0;                      // :182
@@ -476,7 +496,8 @@ int resample_launch(const double *pts, const int64_t *case_offsets, int ncase, i
                     int H, const double *z_final, int W, const double *z_samples, int S, double tol1, double tol2,
                     double p_convert, double *out, void *workspace, hipStream_t st) {
   CFD_REQUIRE(pts && case_offsets && y_final && z_final && z_samples && out && workspace, "NULL pointer");
-  CFD_REQUIRE(ncase > 0 && H > 0 && W > 0 && S > 0 && S <= 2048, "bad sizes ncase=%d H=%d W=%d S=%d", ncase, H, W, S);
+  CFD_REQUIRE(ncase > 0 && ncase <= 65535 && H > 0 && W > 0 && S > 0 && S <= 2048, "bad sizes ncase=%d H=%d W=%d S=%d",
+              ncase, H, W, S);
   CFD_REQUIRE((int64_t)H * W < (1LL << 31), "grid too large");
   CFD_REQUIRE(total >= 0 && total < (1LL << 31), "total_points %lld out of range", (long long)total);
   CFD_REQUIRE(tol1 >= 0.0 && tol2 >= 0.0, "negative tolerance");
@@ -499,13 +520,17 @@ int resample_launch(const double *pts, const int64_t *case_offsets, int ncase, i
   CFD_HIP(hipMemsetAsync(cnt, 0, (size_t)(L.o_cell - L.o_cnt), st));
   const int pblocks = cdiv(total, 256);
   if (pblocks > 0) {
-    hipLaunchKernelGGL(points_pass_kernel, dim3(pblocks), dim3(256), 0, st, pts, case_offsets, ncase, total, z_samples,
-                       S, tol1, tol2, sacc, scnt, bbox);
+    // blocks per case from the AVERAGE case size (the per-case sizes live on the device): ~8 points per thread
+    int64_t K = (total / ncase + 2047) / 2048;
+    K = K < 1 ? 1 : (K > 256 ? 256 : K);
+    const size_t lds = (size_t)4 * S * 8 + (size_t)((2 * S + 1) / 2) * 8 + 4 * 8;
+    hipLaunchKernelGGL(points_pass_kernel, dim3((unsigned)K, ncase), dim3(256), lds, st, pts, case_offsets, z_samples, S,
+                       tol1, tol2, sacc, scnt, bbox);
     CFD_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(case_setup_kernel, dim3(ncase), dim3(256), 3 * S * sizeof(double), st, case_offsets, z_samples, S,
                      z_final, W, (const unsigned long long *)sacc, (const int *)scnt, (const unsigned long long *)bbox,
-                     wall, L.wall_stride, grid, bnd);
+                     wall, L.wall_stride, grid, bnd, tuning(CFD_TUNE_RESAMPLE_DENSITY) > 0 ? tuning(CFD_TUNE_RESAMPLE_DENSITY) / 4.0 : 1.5);
   CFD_LAUNCH_CHECK();
   if (pblocks > 0) {
     hipLaunchKernelGGL(bin_count_kernel, dim3(pblocks), dim3(256), 0, st, pts, case_offsets, ncase, total,
@@ -536,3 +561,4 @@ extern "C" int cfd_resample_nearest(const double *pts, const int64_t *case_offse
   return resample_launch(pts, case_offsets, ncase, total_points, y_final, H, z_final, W, z_samples, S, tol1, tol2,
                          p_convert, out, workspace, (hipStream_t)stream);
 }
+

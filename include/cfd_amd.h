@@ -43,9 +43,11 @@ const char *cfd_last_error(void);
  *   CFD_TUNE_CLASS_ORDER  -1 heuristic | 0 class-major | 1 class-interleaved block order of the sub-pixel classes of a
  *                         transposed convolution (interleaved: the four classes of one pixel tile share L2 lines)
  *   CFD_TUNE_STAGED_OUT   -1 / 1 on where legal | 0 off: bf16 output tiles of the 256-wide kernel leave through LDS as whole
- *                         pixel rows instead of 32-B fragments */
+ *                         pixel rows instead of 32-B fragments
+ *   CFD_TUNE_RESAMPLE_DENSITY  -1 default (6) | n > 0: the resample's cell grid aims at n / 4 points per cell (any value gives
+ *                         the same results; it trades distance evaluations per pixel against extra search rings) */
 typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_WGRAD256 = 2, CFD_TUNE_CLASS_ORDER = 3,
-               CFD_TUNE_STAGED_OUT = 4, CFD_TUNE_COUNT = 5 } cfd_tuning_key;
+               CFD_TUNE_STAGED_OUT = 4, CFD_TUNE_RESAMPLE_DENSITY = 5, CFD_TUNE_COUNT = 6 } cfd_tuning_key;
 int cfd_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -32,7 +32,9 @@ def short(name):
     for k in ("igemm256_kernel", "igemm128n_kernel", "igemm_kernel", "wgrad256_kernel", "wgrad_slab_reduce_kernel",
               "conv_first_wgrad_kernel", "wgrad_kernel", "bn_apply_kernel", "bn_act_bwd_split_kernel", "bn_act_bwd_kernel", "bn_act_kernel",
               "conv_first_kernel", "adam_kernel", "splitk_epilogue_kernel", "tapgemm",
-              "tap_dw_kernel", "tap_dx_kernel", "transpose_weight_kernel", "maxpool2", "nearest_kernel"):
+              "tap_dw_kernel", "tap_dx_kernel", "transpose_weight_kernel", "maxpool2", "nearest_kernel", "points_pass_kernel",
+              "case_setup_kernel", "bin_count_kernel", "bin_scan_kernel", "bin_scatter_kernel", "resample_init_kernel",
+              "bn_stats_kernel", "sdf_"):
         if k in name:
             dt = "<bf16>" if ("DF16b" in name or "bf16" in name or "_Accum" in name) else ("<f32>" if ("If" in name or "float" in name) else "")
             return k + dt
