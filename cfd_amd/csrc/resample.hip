@@ -562,3 +562,69 @@ extern "C" int cfd_resample_nearest(const double *pts, const int64_t *case_offse
                          p_convert, out, workspace, (hipStream_t)stream);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The one entry point that allocates nothing (no counterpart in the reference).  For callers that cannot call
+// hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same kernels as
+// cfd_resample_nearest; the workspace is this file-scope device array instead of a caller-supplied buffer.  Every GPU
+// the library runs on holds its own copy (RS_SCRATCH_BYTES, until the process ends) at its own address, so the address
+// is looked up once per device with that device current, and only that pointer -- never the array's name -- is handed
+// to kernels and memsets.  The array keeps the last call's contents: resample_launch re-initialises every accumulator
+// and counter it reads (resample_init_kernel, the memset of the cell counts), so nothing has to be cleared here.
+// Calls that overlap on one GPU (two streams, two threads) share the array and RACE: serialise them.
+// ---------------------------------------------------------------------------------------------------------------
+#include <mutex>
+
+namespace cfd {
+constexpr size_t RS_SCRATCH_BYTES = 6u << 20;     // 6 MiB per GPU; e.g. 64 cases x 1024 points, 64x512 grid, 101 slices = 3.7 MiB
+constexpr int RS_MAX_DEVICES = 64;
+static __device__ __align__(256) unsigned char scratch[RS_SCRATCH_BYTES];
+static void *g_scratch_ptr[RS_MAX_DEVICES];       // per device: device address of `scratch`, 0 = not looked up yet
+static std::mutex g_scratch_mutex;
+
+__global__ void copy_valid_slices_kernel(const double *__restrict__ wall, int64_t wall_stride, int S, int W, int ncase,
+                                         int *__restrict__ out) {
+  const int cs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cs < ncase) out[cs] = *(const int *)(wall + (int64_t)cs * wall_stride + 2 * S + 2 * W);
+}
+}  // namespace cfd
+
+extern "C" int64_t cfd_resample_noalloc_max_bytes(void) { return (int64_t)RS_SCRATCH_BYTES; }
+
+extern "C" int cfd_resample_nearest_noalloc(const double *pts, const int64_t *case_offsets, int ncase,
+                                            int64_t total_points, const double *y_final, int H, const double *z_final,
+                                            int W, const double *z_samples, int S, double tol1, double tol2,
+                                            double p_convert, double *out, int *valid_slices, void *stream) {
+  CFD_REQUIRE(ncase > 0 && W > 0 && S > 0 && total_points >= 0, "bad sizes ncase=%d W=%d S=%d total_points=%lld", ncase,
+              W, S, (long long)total_points);
+  const int64_t need = rs_layout(ncase, W, S, total_points).bytes;
+  CFD_REQUIRE(need <= (int64_t)RS_SCRATCH_BYTES,
+              "cfd_resample_nearest_noalloc: this call needs %lld bytes of scratch, the built-in buffer holds %lld "
+              "(ncase=%d W=%d S=%d total_points=%lld); use cfd_resample_nearest with a caller-supplied workspace",
+              (long long)need, (long long)RS_SCRATCH_BYTES, ncase, W, S, (long long)total_points);
+  int dev = -1;
+  CFD_HIP(hipGetDevice(&dev));
+  CFD_REQUIRE(dev >= 0 && dev < RS_MAX_DEVICES, "device index %d out of range", dev);
+  void *ws = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+      void *p = nullptr;
+      CFD_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));     // the current device's copy of the array
+      CFD_REQUIRE(p != nullptr, "hipGetSymbolAddress returned a null address");
+      g_scratch_ptr[dev] = p;
+    }
+    ws = g_scratch_ptr[dev];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = resample_launch(pts, case_offsets, ncase, total_points, y_final, H, z_final, W, z_samples, S, tol1, tol2,
+                                 p_convert, out, ws, st);
+  if (rc != CFD_OK) return rc;
+  if (valid_slices) {
+    const RsLayout L = rs_layout(ncase, W, S, total_points);
+    hipLaunchKernelGGL(copy_valid_slices_kernel, dim3(cdiv(ncase, 64)), dim3(64), 0, st,
+                       (const double *)((char *)ws + L.o_wall), L.wall_stride, S, W, ncase, valid_slices);
+    CFD_LAUNCH_CHECK();
+  }
+  return CFD_OK;
+}

@@ -401,6 +401,17 @@ class ResampleJob:
               "cfd_resample_nearest")
         return self.out
 
+    def run_noalloc(self, valid_slices: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """the same call through cfd_resample_nearest_noalloc: the library's built-in scratch instead of self.ws, no
+        allocation anywhere (valid_slices: optional int32 (ncase,) device tensor the caller owns)"""
+        if valid_slices is not None:
+            _numel(valid_slices, self.ncase, "valid_slices", torch.int32)
+        check(_lib.load().cfd_resample_nearest_noalloc(_ptr(self.pts), _ptr(self.offs), self.ncase, self.n_points,
+                                                       _ptr(self.yf), self.H, _ptr(self.zf), self.W, _ptr(self.zs),
+                                                       N_SLICES, TOL_1, TOL_2, P_CONVERT, _ptr(self.out),
+                                                       _ptr(valid_slices), _stream()), "cfd_resample_nearest_noalloc")
+        return self.out
+
     def algorithmic_bytes(self) -> int:
         """HBM bytes = input points + 5 output columns = 40 B x (N_pts + H*W) per case"""
         return 40 * (self.n_points + self.ncase * self.H * self.W)

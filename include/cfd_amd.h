@@ -279,6 +279,21 @@ int cfd_resample_nearest(const double *pts, const int64_t *case_offsets, int nca
                          const double *y_final, int H, const double *z_final, int W, const double *z_samples, int S,
                          double tol1, double tol2, double p_convert, double *out, void *workspace, void *stream);
 
+/* cfd_resample_nearest WITHOUT a workspace argument and without any allocation.  No counterpart in the reference: it
+ * exists for callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  The scratch is a fixed device array inside the library (cfd_resample_noalloc_max_bytes() =
+ * 6 MiB per GPU, held until the process ends; 64 cases x 1024 points on a 64x512 grid with 101 slices need 3.7 MiB):
+ * a call whose cfd_resample_workspace_bytes(...) exceeds it is refused with CFD_EINVAL and a message naming both
+ * numbers.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU RACE -- serialise them.
+ *   valid_slices  int [ncase] (device, may be NULL): per case the number of valid wall slices (0: np.interp would
+ *                 have raised, :210) -- what the workspace's status words tell the caller of cfd_resample_nearest
+ * All other arguments as cfd_resample_nearest; same kernels, same results bit for bit. */
+int64_t cfd_resample_noalloc_max_bytes(void);
+int cfd_resample_nearest_noalloc(const double *pts, const int64_t *case_offsets, int ncase, int64_t total_points,
+                                 const double *y_final, int H, const double *z_final, int W, const double *z_samples,
+                                 int S, double tol1, double tol2, double p_convert, double *out, int *valid_slices,
+                                 void *stream);
+
 /* Host-side text form of the resample's result table (no device work, no stream).
  * Replaces `df_out.to_csv(output_csv, index=False)`, pixels_coords_testing.py:223-226 (pandas' writer: every fp64 as
  * repr(float) = shortest round-trip decimal in CPython's layout, NaN as the empty field).  SAME BYTES as pandas, without
