@@ -7,9 +7,9 @@ Counterpart of `utils.load_data` (/root/reference/utils.py:64-107): per case, co
 
 The per-case arithmetic runs on the GPU (`ops.dataset_grids`, csrc/dataset.hip): sign mask, DeltaP in
 numpy's summation order, and the signed distance.  The reference's SDF is `skfmm.distance` (scikit-fmm, a
-fast-marching Eikonal solver; absent here and unpinned in the reference): the kernel keeps its contract --
-distance to the zero contour half-way between cells of opposite sign, negative where phi<0 -- with an exact
-Euclidean distance transform (PARITY UNPINNED; checked bit-for-bit against oracle/dataset.py).
+fast-marching Eikonal solver; absent here and unpinned in the reference): the kernel implements scikit-fmm's
+published scheme (order 2: interpolated frozen band, heap-ordered upwind marching; PARITY UNPINNED, see
+DESIGN.md §4; checked bit-for-bit against the independent CPU restatement oracle/sdf_fmm.c).
 """
 from __future__ import annotations
 

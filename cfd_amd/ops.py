@@ -451,8 +451,9 @@ def csv_format_rows(rows: np.ndarray) -> bytes:
 
 def dataset_grids(p: np.ndarray, cell: float, device="cuda", return_device: bool = False):
     """p: (ncase, H, W) fp64 `p_convert` grids.  Returns (sdf (ncase,H,W) fp64, delta_p (ncase,) fp64): the model
-    input and DeltaP of utils.load_data (utils.py:89-103), computed on the GPU.  Raises ValueError for a case without
-    a zero contour (all fluid or all solid), as skfmm.distance does."""
+    input and DeltaP of utils.load_data (utils.py:89-103), computed on the GPU; the signed distance is scikit-fmm's
+    fast-marching scheme (order 2), one thread per case.  Raises ValueError for a case without a zero contour (all
+    fluid or all solid), as skfmm.distance does."""
     lib = _lib.load()
     p = np.ascontiguousarray(p, dtype=np.float64)
     if p.ndim != 3:
@@ -462,11 +463,15 @@ def dataset_grids(p: np.ndarray, cell: float, device="cuda", return_device: bool
     sdf = torch.empty((n, H, W), dtype=torch.float64, device=device)
     dp = torch.empty(n, dtype=torch.float64, device=device)
     flags = torch.empty(n, dtype=torch.int32, device=device)
-    ws = torch.empty(lib.cfd_dataset_workspace_bytes(n, H, W) // 4, dtype=torch.int32, device=device)
+    wsb = lib.cfd_dataset_workspace_bytes(n, H, W)
+    if wsb < 0:
+        check(-1, "cfd_dataset_workspace_bytes")
+    ws = torch.empty(wsb, dtype=torch.uint8, device=device)
     check(lib.cfd_dataset_grids(_ptr(pd_), n, H, W, float(cell), _ptr(sdf), _ptr(dp), _ptr(flags), _ptr(ws), _stream()),
           "cfd_dataset_grids")
-    if bool((flags != 3).any().item()):
-        raise ValueError("the array phi contains no zero contour (no zero level set)")
+    fl = flags.cpu().numpy()
+    if ((fl & 3) != 3).any():
+        raise ValueError("the array phi contains no zero contour (no zero level set)")      # skfmm/pfmm.py
     if return_device:
         return sdf, dp
     return sdf.cpu().numpy(), dp.cpu().numpy()

@@ -306,13 +306,16 @@ int64_t cfd_csv_format_rows(const double *rows, int64_t n_rows, int n_cols, char
 /* ------------------------------------------------------------------------------------
  * Dataset build: what utils.load_data computes per case after parsing the CSV (utils.py:89-103).
  *   p            fp64 [ncase][H][W]: the `p_convert` column reshaped (device)
- *   sdf          fp64 [ncase][H][W]: signed distance of pts = (p > 0 ? -1 : +1) with cell size `cell` (= 4/H,
- *                utils.py:101): the model input.  Exact Euclidean distance to the contour half a cell from either
- *                centre; skfmm.distance (fast marching, absent here) differs by its discretisation error.
+ *   sdf          fp64 [ncase][H][W]: skfmm.distance(pts, dx = cell) with pts = (p > 0 ? -1 : +1) and cell = 4/H
+ *                (utils.py:100-103): the model input.  scikit-fmm's fast-marching scheme, order 2, no mask (frozen band by
+ *                per-axis linear interpolation combined harmonically, heap-ordered upwind updates); scikit-fmm itself is
+ *                absent here, so the scheme is restated from its published source (PARITY UNPINNED) and checked bit for
+ *                bit against the independent CPU restatement oracle/sdf_fmm.c.  One thread marches one case.
  *   delta_p      fp64 [ncase]: mean(p[:,0]) - mean(p[:,-1]) in numpy's summation order (utils.py:97)
- *   flags        int  [ncase]: bit 0 = some cell is fluid, bit 1 = some cell is solid; a case with flags != 3 has
- *                no zero contour (skfmm raises there; the host mirror does too)
- *   workspace    cfd_dataset_workspace_bytes(ncase, H, W) bytes
+ *   flags        int  [ncase]: bit 0 = some cell is fluid, bit 1 = some cell is solid; a case with (flags & 3) != 3 has
+ *                no zero contour (skfmm raises ValueError there; the host mirror does too)
+ *   workspace    cfd_dataset_workspace_bytes(ncase, H, W) bytes (17 B per cell: heap keys, heap cells, heap positions,
+ *                cell states)
  * ---------------------------------------------------------------------------------- */
 int64_t cfd_dataset_workspace_bytes(int ncase, int H, int W);
 int cfd_dataset_grids(const double *p, int ncase, int H, int W, double cell, double *sdf, double *delta_p, int *flags,

@@ -21,6 +21,8 @@ Pinning status (see DESIGN.md "Oracle"):
   fixtures or golden outputs for these graphs; every Keras default used is
   listed in ``oracle/keras_semantics.py`` so one place needs fixing if a later
   session can run real Keras.
-* ``oracle.sdf``       -- restates ``skfmm.distance`` (scikit-fmm, absent here).
-  PARITY UNPINNED, checked against analytic shapes only.
+* ``oracle.dataset``   -- restates ``utils.load_data``'s per-case arithmetic; its signed distance
+  (``oracle/sdf_fmm.c``, built by ``oracle/build.py``) restates scikit-fmm's published fast-marching
+  scheme (scikit-fmm is absent here).  PARITY UNPINNED, checked against analytic shapes and
+  hand-computed values of the scheme only.
 """

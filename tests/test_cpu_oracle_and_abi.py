@@ -112,6 +112,40 @@ def test_oracle_signed_distance_analytic():
     assert ((d < 0) == (phi < 0)).all()
     with pytest.raises(ValueError):
         OD.signed_distance(np.ones((8, 8)), dx)
+    # fast marching stays within its discretisation error of the exact Euclidean transform (the round-1 yardstick)
+    assert np.abs(d - OD.signed_distance_edt(phi, dx)).max() <= 0.5 * dx
+
+
+def test_oracle_fast_marching_hand_computed_values():
+    """oracle/sdf_fmm.c against values of scikit-fmm's published scheme worked out by hand (parity unpinned: scikit-fmm is
+    absent).  Quadrant of fluid in an 8x8 grid, dx = 1:
+      * band cell beside a straight wall: dx * 1/(1-(-1)) = 0.5; in the corner both axes cross: sqrt(1/(4+4)) = 0.35355
+      * first marched cell diagonal to the corner: both axes second order with value1 = value2 = 0.5 -> tp = 0.5,
+        2 * 9/4 (d - 0.5)^2 = 1 -> d = 0.5 + sqrt(2)/3
+      * along a straight wall the second-order update is exact: 0.5, 1.5, 2.5 ... (and nearly so away from the corner)
+      * symmetric input -> symmetric field; sign follows phi"""
+    from oracle import dataset as OD
+    phi = np.ones((8, 8)); phi[:4, :4] = -1.0
+    d = OD.signed_distance(phi, 1.0)
+    assert d[3, 0] == -0.5 and d[0, 3] == -0.5 and d[4, 0] == 0.5 and d[0, 4] == 0.5
+    assert abs(d[3, 3] + 1 / (2 * np.sqrt(2))) < 1e-15
+    assert abs(d[4, 4] - (0.5 + np.sqrt(2) / 3)) < 1e-14
+    assert abs(d[5, 0] - 1.5) < 1e-6 and abs(d[6, 0] - 2.5) < 1e-6        # far from the corner: the straight-wall values
+    straight = np.ones((8, 3)); straight[:4] = -1.0
+    assert np.allclose(OD.signed_distance(straight, 1.0)[:, 1], [-3.5, -2.5, -1.5, -0.5, 0.5, 1.5, 2.5, 3.5], rtol=0, atol=1e-12)
+    assert np.array_equal(d, d.T) and ((d < 0) == (phi < 0)).all()
+    # speckled masks reach the negative-discriminant branch (scikit-fmm falls back to the parabola's minimum): finite,
+    # correctly signed, and within a few cells of the exact transform
+    rng = np.random.default_rng(1)
+    sp = np.ones((32, 64)); sp[8:24] = -1.0
+    sp[rng.random(sp.shape) < 0.05] *= -1.0
+    ds = OD.signed_distance(sp, 1.0)
+    assert np.isfinite(ds).all() and ((ds < 0) == (sp < 0)).all()
+    assert np.abs(ds - OD.signed_distance_edt(sp, 1.0)).max() <= 2.0
+    # a batch equals its cases one by one, bit for bit
+    phi2 = np.ones((8, 8)); phi2[2:6, 1:7] = -1.0
+    b = OD.signed_distance(np.stack([phi, phi2]), 0.25)
+    assert np.array_equal(b[0], OD.signed_distance(phi, 0.25)) and np.array_equal(b[1], OD.signed_distance(phi2, 0.25))
 
 
 def test_oracle_metrics_pinned_to_sklearn():

@@ -415,8 +415,9 @@ def test_resample_no_slices_raises():
 
 @pytest.mark.parametrize("H,W", [(64, 512), (128, 1024), (16, 40)])
 def test_dataset_grids_bit_exact(H, W):
-    """sign mask -> signed distance + DeltaP (utils.py:89-103) on the GPU vs the numpy/scipy restatement
-    (oracle/dataset.py): integer distance transform + one fp64 sqrt, numpy's summation order -> bit-exact"""
+    """sign mask -> signed distance + DeltaP (utils.py:89-103) on the GPU vs the CPU restatement (oracle/dataset.py,
+    oracle/sdf_fmm.c): two independent implementations of scikit-fmm's fast-marching scheme that pop the heap in the same
+    total order and round every expression alike, numpy's summation order for DeltaP -> bit-exact"""
     from cfd_amd import ops, synthetic
     from oracle import dataset as OD
     ps = []
@@ -429,8 +430,17 @@ def test_dataset_grids_bit_exact(H, W):
     q4[H // 2 - 2:H // 2 + 2, W // 3:W // 3 + 5] = 0.0
     q4[0, :7] = 0.5
     ps.append(q4)
+    # speckled masks (isolated solid cells in the fluid and fluid cells in the wall, as a noisy p field gives): these
+    # reach the negative-discriminant branch of the quadratic update
+    rng = np.random.default_rng(H)
+    q5 = ps[1].copy()
+    q5[rng.random(q5.shape) < 0.03] = 0.0
+    q5[rng.random(q5.shape) < 0.01] = 1.0
+    ps.append(q5)
+    ps.append(np.where(rng.random((H, W)) < 0.5, 1.0, 0.0))           # pure noise
     p = np.stack(ps)
     sdf, dp = ops.dataset_grids(p, cell=4.0 / H)
+    assert np.isfinite(sdf).all()
     for i in range(len(ps)):
         ref_sdf, _p, _u, ref_dp = OD.grids_from_table(ps[i].ravel(), ps[i].ravel(), H, W)
         assert np.array_equal(sdf[i].view(np.uint64), ref_sdf.view(np.uint64)), f"sdf case {i}"
