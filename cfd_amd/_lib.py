@@ -71,6 +71,8 @@ SIGNATURES = {
     "cfd_field_loss": (_i, [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp, _i, _vp]),
     "cfd_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _f, _vp]),
     "cfd_bn_update_moving": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "cfd_bn_update_moving_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
+    "cfd_zero_ranges": (_i, [_vp, _vp, _i, _i64, _vp]),
     "cfd_tap_scatter_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "cfd_tap_dx": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
     "cfd_tap_dw": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp]),

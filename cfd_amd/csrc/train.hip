@@ -497,6 +497,35 @@ __global__ void bn_update_moving_kernel(float *__restrict__ mm, float *__restric
   mm[c] = a; mv[c] = q;
 }
 
+// the same for up to 16 BatchNorm layers in one launch (a discriminator update touches four: 12 launches of ~8 us per
+// training step became 3); blockIdx.y = layer
+constexpr int BN_MULTI_MAX = 16;
+struct BnMultiArgs {
+  float *mm[BN_MULTI_MAX], *mv[BN_MULTI_MAX];
+  const float *mean[BN_MULTI_MAX], *var[BN_MULTI_MAX];
+  int C[BN_MULTI_MAX];
+};
+__global__ void bn_update_moving_multi_kernel(BnMultiArgs a, int B, float mom) {
+  const int l = blockIdx.y, C = a.C[l];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float m = a.mm[l][c], q = a.mv[l][c];
+  const float *mean = a.mean[l], *var = a.var[l];
+  for (int b = 0; b < B; ++b) {
+    m = m * mom + mean[(size_t)b * C + c] * (1.f - mom);
+    q = q * mom + var[(size_t)b * C + c] * (1.f - mom);
+  }
+  a.mm[l][c] = m; a.mv[l][c] = q;
+}
+
+// base[off .. off + cnt) = 0 for every (off, cnt) pair of a device-resident table: the gradient tensors that kernels
+// ACCUMULATE into (bias / BatchNorm / first- and last-layer gradients), in one launch instead of a memset of the whole
+// flat gradient buffer (512 MB for the U generator) -- the GEMM-shaped weight gradients are plain stores
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float *__restrict__ base, const int64_t *__restrict__ ranges) {
+  const int64_t off = ranges[2 * blockIdx.y], cnt = ranges[2 * blockIdx.y + 1];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) base[off + i] = 0.f;
+}
+
 // y = x * keep * scale over a dense [rows][C] tensor (Dropout(0.5) after fc1, DeltaP/models/generator.py:42; same
 // kernel applies the mask to the gradient in the backward pass)
 template <typename T>
@@ -872,6 +901,33 @@ extern "C" int cfd_bn_update_moving(float *moving_mean, float *moving_var, const
   CFD_REQUIRE(moving_mean && moving_var && mean && var && B > 0 && C > 0, "bad arguments");
   hipLaunchKernelGGL(bn_update_moving_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, moving_mean,
                      moving_var, mean, var, B, C, momentum);
+  CFD_LAUNCH_CHECK();
+  return CFD_OK;
+}
+
+extern "C" int cfd_bn_update_moving_multi(int nlayers, float *const *moving_mean, float *const *moving_var,
+                                          const float *const *mean, const float *const *var, const int *C, int B,
+                                          float momentum, void *stream) {
+  CFD_REQUIRE(nlayers > 0 && nlayers <= BN_MULTI_MAX && moving_mean && moving_var && mean && var && C && B > 0,
+              "bad arguments (at most %d layers per call)", BN_MULTI_MAX);
+  BnMultiArgs a;
+  int cmax = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    CFD_REQUIRE(moving_mean[l] && moving_var[l] && mean[l] && var[l] && C[l] > 0, "layer %d: NULL pointer or C <= 0", l);
+    a.mm[l] = moving_mean[l]; a.mv[l] = moving_var[l]; a.mean[l] = mean[l]; a.var[l] = var[l]; a.C[l] = C[l];
+    cmax = C[l] > cmax ? C[l] : cmax;
+  }
+  hipLaunchKernelGGL(bn_update_moving_multi_kernel, dim3((cmax + 255) / 256, nlayers), dim3(256), 0, (hipStream_t)stream, a,
+                     B, momentum);
+  CFD_LAUNCH_CHECK();
+  return CFD_OK;
+}
+
+extern "C" int cfd_zero_ranges(float *base, const int64_t *ranges, int n, int64_t max_count, void *stream) {
+  CFD_REQUIRE(base && ranges && n > 0 && n <= 65535 && max_count > 0, "bad arguments");
+  int bx = (int)((max_count + 2047) / 2048);
+  bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, base, ranges);
   CFD_LAUNCH_CHECK();
   return CFD_OK;
 }

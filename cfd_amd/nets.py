@@ -143,6 +143,8 @@ class Generator(_Net):
                          [(f"d{i}", f) for i, (f, _d) in enumerate(a["dec"], 1)]
         super().__init__(specs, device, dtype, seed)
         self.params.no_transpose = frozenset({"e1.kernel", "out.kernel"})
+        self.params.stored_grads = frozenset(n for n in self.params.specs
+                                             if n.endswith(".kernel") and n not in ("e1.kernel", "out.kernel"))
 
     def dropout_shapes(self, B: int):
         h, w, out = self.H // 64, self.W // 64, []
@@ -212,6 +214,7 @@ class Generator(_Net):
         ready = ready or (lambda _name: None)
         self.check_image(x, dz)
         P, a, B = self.params, self.a, x.shape[0]
+        P.wait_transposed()
         pl = self.plan(B)
         sums = self.bn_bwd_sums(pl, B)
         enc, dec = a["enc"], a["dec"]
@@ -299,6 +302,7 @@ class Discriminator(_Net):
         super().__init__(specs, device, dtype, seed)
         self.params.no_transpose = frozenset({"c1.kernel", "c6.kernel"})
         self.params.flip_taps = frozenset({"c5.kernel"})
+        self.params.stored_grads = frozenset(f"c{i}.kernel" for i in range(2, 6))
 
     @property
     def patch_shape(self):
@@ -337,9 +341,8 @@ class Discriminator(_Net):
     def update_moving(self, B: int) -> None:
         """moving statistics <- batch statistics of the forward that just ran (momentum 0.99)"""
         pl = self.plan(B)
-        for i in range(2, 6):
-            ops.bn_update_moving(self.params.m(f"c{i}.bn.moving_mean"), self.params.m(f"c{i}.bn.moving_var"),
-                                 pl[f"mean_c{i}"], pl[f"var_c{i}"])
+        ops.bn_update_moving_multi([(self.params.m(f"c{i}.bn.moving_mean"), self.params.m(f"c{i}.bn.moving_var"),
+                                     pl[f"mean_c{i}"], pl[f"var_c{i}"]) for i in range(2, 6)])
 
     def backward(self, dlogits: torch.Tensor, src: torch.Tensor, tgt: torch.Tensor, train_convs: bool = True,
                  want_input_grad: bool = False):
@@ -350,6 +353,7 @@ class Discriminator(_Net):
         P, B = self.params, src.shape[0]
         if tuple(dlogits.shape) != (B,) + self.patch_shape:
             raise ValueError(f"dlogits must be {(B,) + self.patch_shape}, got {tuple(dlogits.shape)}")
+        P.wait_transposed()
         pl = self.plan(B)
         sums = self.bn_bwd_sums(pl, B)
         c5 = pl["c5"]
@@ -402,6 +406,7 @@ class CnnRegressor(_Net):
             specs += [Spec(name + ".kernel", "dense", (ci, co)), Spec(name + ".bias", "vec", (co,))]
         super().__init__(specs, device, dtype, seed)
         self.params.no_transpose = frozenset({"g1.kernel", "fc3.kernel"})
+        self.params.stored_grads = frozenset(n + ".kernel" for n in ("g3", "g4", "g6", "fc1", "fc2"))
 
     def forward(self, x: torch.Tensor, training: bool = False, drop_mask: Optional[torch.Tensor] = None,
                 seed: int = 0, sample0: int = 0):
@@ -443,6 +448,7 @@ class CnnRegressor(_Net):
         P, B = self.params, x.shape[0]
         if tuple(dy.shape) != (B, 1):
             raise ValueError(f"dy must be ({B}, 1), got {tuple(dy.shape)}")
+        P.wait_transposed()
         pl = self.plan(B)
         dt = self.dtype
         H, W = self.H, self.W

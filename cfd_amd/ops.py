@@ -664,6 +664,28 @@ def bn_update_moving(mm, mv, mean, var, momentum=0.99):
           "cfd_bn_update_moving")
 
 
+def bn_update_moving_multi(layers, momentum=0.99):
+    """layers: list of (moving_mean, moving_var, mean (B,C), var (B,C)) -- one launch for all of them (<= 16)"""
+    n = len(layers)
+    B = layers[0][2].shape[0]
+    arr = lambda k: (C.c_void_p * n)(*[_dev(l[k]).data_ptr() for l in layers])
+    cs = (C.c_int * n)(*[l[2].shape[1] for l in layers])
+    for mm, mv, mean, var in layers:
+        Cc = mean.shape[1]
+        _need(mean.shape[0] == B and tuple(var.shape) == (B, Cc), "bn_update_moving_multi: one batch size, var like mean")
+        for t, nn in ((mm, Cc), (mv, Cc), (mean, B * Cc), (var, B * Cc)):
+            _numel(t, nn, "bn_update_moving operand", torch.float32)
+    check(_lib.load().cfd_bn_update_moving_multi(n, arr(0), arr(1), arr(2), arr(3), cs, B, momentum, _stream()),
+          "cfd_bn_update_moving_multi")
+
+
+def zero_ranges(base: torch.Tensor, table: torch.Tensor, max_count: int) -> None:
+    """base[off:off+cnt] = 0 for every (off, cnt) row of the int64 device `table` (validated when it was built)"""
+    _need(base.dtype == torch.float32 and base.is_contiguous() and table.dtype == torch.int64 and table.dim() == 2
+          and table.shape[1] == 2 and table.is_contiguous(), "zero_ranges: fp32 base, int64 (n, 2) table")
+    check(_lib.load().cfd_zero_ranges(_ptr(base), _ptr(table), table.shape[0], int(max_count), _stream()), "cfd_zero_ranges")
+
+
 def tap_scatter_grad(dz, dtaps, B, Hi, Wi, geom):
     # geom 0: dz is the (B,2Hi,2Wi) image gradient of a stride-2 transposed conv; geom 1: (B,Hi,Wi) of a stride-1 conv
     _numel(dz, B * Hi * Wi * (4 if geom == 0 else 1), "tap_scatter_grad dz", torch.float32)

@@ -99,16 +99,69 @@ class ParamStore:
         shp = (s.packed_shape[-1],) + tuple(s.packed_shape[1:-1]) + (s.packed_shape[0],)
         return self.compute_t[s.offset:s.offset + s.numel].view(shp)
 
-    def refresh_transposed(self) -> None:
+    def refresh_transposed(self, side_stream: bool = False) -> None:
+        """compute_t <- transposed compute copy (after the weights changed).  side_stream=True (the train steps): the
+        transposes are HBM-bound and only the NEXT backward reads them, so they run on a side stream behind everything
+        enqueued so far and overlap the MFMA-bound kernels the caller enqueues next; `wait_transposed()` (called by
+        every backward) joins them."""
         if getattr(self, "compute_t", None) is None:
             return
+        if side_stream and self.master.is_cuda:
+            if self._t_stream is None:
+                self._t_stream = torch.cuda.Stream()
+            self.wait_transposed()                     # never two refreshes in flight
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._t_stream):
+                self._t_stream.wait_event(ev)
+                self._transpose_all()
+                self._t_done = torch.cuda.Event()
+                self._t_done.record()
+        else:
+            self.wait_transposed()
+            self._transpose_all()
+
+    def _transpose_all(self) -> None:
         for name, s in self.specs.items():
             if s.kind in ("conv", "convT", "dense") and name not in self.no_transpose:
                 flip = s.kind == "conv" and s.packed_shape[1] * s.packed_shape[2] in (9,) or name in self.flip_taps
                 ops.transpose_weight(self.c(name), bool(flip), out=self.t(name))
 
+    def wait_transposed(self) -> None:
+        """the current stream waits for a refresh_transposed(side_stream=True) still in flight"""
+        if self._t_done is not None:
+            torch.cuda.current_stream().wait_event(self._t_done)
+            self._t_done = None
+
+    def zero_grad(self) -> None:
+        """Clear what the backward ACCUMULATES into: every trainable tensor except the GEMM-shaped weight gradients
+        named in `stored_grads`, which ops.conv_wgrad overwrites (or zeroes itself on its atomic path).  One launch
+        over a device-resident range table instead of a memset of the whole flat buffer."""
+        if self._zero_table is None:
+            ranges = []
+            for name, s in self.specs.items():
+                if s.offset >= self.n_trainable or name in self.stored_grads:
+                    continue
+                span = (s.numel + ALIGN - 1) // ALIGN * ALIGN            # the padding behind a tensor may be cleared too
+                if ranges and ranges[-1][0] + ranges[-1][1] == s.offset:
+                    ranges[-1][1] += span
+                else:
+                    ranges.append([s.offset, span])
+            for off, cnt in ranges:
+                if off < 0 or off + cnt > self.n_trainable:
+                    raise RuntimeError("zero_grad: range outside the gradient buffer")
+            self._zero_max = max((c for _o, c in ranges), default=0)
+            self._zero_table = torch.tensor(ranges or [[0, 0]], dtype=torch.int64, device=self.device).reshape(-1, 2)
+        if self._zero_max > 0:
+            ops.zero_ranges(self.grad, self._zero_table, self._zero_max)
+
     no_transpose: frozenset = frozenset()
     flip_taps: frozenset = frozenset()
+    stored_grads: frozenset = frozenset()      # kernels whose gradient ops.conv_wgrad writes (set by the nets)
+    _t_stream = None
+    _t_done = None
+    _zero_table = None
+    _zero_max = 0
 
     def refresh_compute(self) -> None:
         """compute copy <- master (after loading weights; the fused Adam kernel keeps it in sync later)"""

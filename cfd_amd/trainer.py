@@ -350,7 +350,7 @@ class DiscriminatorTrainer:
         D's short backward cannot hide by itself."""
         d, P = self.d, self.d.params
         B = src.shape[0]
-        P.grad.zero_()
+        P.zero_grad()
         self.loss.zero_()
         logits = d.forward(src, tgt, training=True, want_logits=True)
         dz = d.buf(d.plan(B), "dlogits", logits.shape, torch.float32)
@@ -372,7 +372,7 @@ class DiscriminatorTrainer:
         self.opt.step(self.dp.grad_scale, segs)
         self.dp.gather_params(P, segs)
         if self.train_convs:
-            P.refresh_transposed()
+            P.refresh_transposed(side_stream=True)
         join_averages()
         self.d.update_moving(B)
         self.dp.average_async(P.master[P.n_trainable:P.n_total])
@@ -424,9 +424,9 @@ class GanTrainer:
         B = src.shape[0]
         self.step_count += 1
         seed = self.step_count if seed is None else seed
-        g.params.grad.zero_()
+        g.params.zero_grad()
         fake, dz_d = self._forward_losses(src, label, tgt, masks, seed, sample0, True, True, before_d)
-        d.params.grad.zero_()      # after a pending D step (before_d) has consumed its gradients
+        d.params.zero_grad()       # after a pending D step (before_d) has consumed its gradients
         dfake = d.backward(dz_d, src, fake, train_convs=False, want_input_grad=True)
         # D's BN gradients are complete: overlap their all-reduce (and G's, bucket by bucket) with G's backward
         self.dp.reduce_range_async(d.params, self.opt_dbn.lo, self.opt_dbn.hi)
@@ -441,7 +441,7 @@ class GanTrainer:
         self.opt_g.step(self.dp.grad_scale, segs)
         self.dp.gather_params(g.params, segs)
         self.opt_dbn.step(self.dp.grad_scale, self.dp.take(d.params, self.opt_dbn.lo, self.opt_dbn.hi))
-        g.params.refresh_transposed()
+        g.params.refresh_transposed(side_stream=True)
         join_averages()
         d.update_moving(B)
         self.dp.average_async(d.params.master[d.params.n_trainable:d.params.n_total])
@@ -478,7 +478,7 @@ class CnnTrainer:
         B = x.shape[0]
         self.step_count += 1
         seed = self.step_count if seed is None else seed
-        P.grad.zero_()
+        P.zero_grad()
         self.loss.zero_()
         pred = c.forward(x, training=True, drop_mask=drop_mask, seed=seed, sample0=sample0)
         dy = c.buf(c.plan(B), "dy", pred.shape, torch.float32)
@@ -489,7 +489,7 @@ class CnnTrainer:
         segs = self.dp.take(P, 0, P.n_trainable)
         self.opt.step(self.dp.grad_scale, segs)
         self.dp.gather_params(P, segs)
-        P.refresh_transposed()
+        P.refresh_transposed(side_stream=True)
         return self.weight * float(self.loss.item())
 
     def sync_state(self) -> None:

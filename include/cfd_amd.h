@@ -242,6 +242,17 @@ int cfd_adam_step(float *w, const float *g, float *m, float *v, void *w_compute,
 int cfd_bn_update_moving(float *moving_mean, float *moving_var, const float *mean, const float *var, int B, int C,
                          float momentum, void *stream);
 
+/* cfd_bn_update_moving for up to 16 BatchNorm layers in one launch (the discriminator's four per update).  The arrays
+ * are HOST arrays of `nlayers` device pointers / channel counts. */
+int cfd_bn_update_moving_multi(int nlayers, float *const *moving_mean, float *const *moving_var,
+                               const float *const *mean, const float *const *var, const int *C, int B, float momentum,
+                               void *stream);
+/* base[off .. off+cnt) = 0 for each of the n (off, cnt) pairs in `ranges` (DEVICE int64 [n][2]; max_count = the largest
+ * cnt, sizes the grid): what a train step must clear before its backward -- the gradient tensors that kernels
+ * accumulate into (biases, BatchNorm gamma/beta, first/last layers); the GEMM weight gradients are stored, not added
+ * (no counterpart in the reference; Keras zeroes nothing because it owns its gradient buffers). */
+int cfd_zero_ranges(float *base, const int64_t *ranges, int n, int64_t max_count, void *stream);
+
 /* One-output-channel layers (generator `out` Conv2DTranspose, discriminator c6 Conv2D): backward.
  * geom 0: Conv2DTranspose k4 s2; geom 1: Conv2D k4 s1 'same'.  dtaps fp32 [B*Hi*Wi][16]. */
 int cfd_tap_scatter_grad(const float *dz, float *dtaps, int B, int Hi, int Wi, int geom, void *stream);
