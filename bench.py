@@ -108,7 +108,7 @@ class TrainJob:
         they are enqueued between a D update's all-reduce launch and its Adam step: same arithmetic as the
         reference's order, with D's gradient exchange hidden behind them when world > 1."""
         self.dtr.begin(x, y, 1.0)                                         # d_model.train_on_batch([A,B], ones) ...
-        fake = self.g.forward(x, seed=2 * step, sample0=sample0)          # generate_fake_samples (utils.py:52-62)
+        fake = self.g.forward(x, seed=2 * step, sample0=sample0, inference=True)   # generate_fake_samples (utils.py:52-62)
         self.dtr.finish()                                                 # ... its all-reduce, Adam
         self.dtr.begin(x, fake, 0.0)                                      # d_model.train_on_batch([A,fake], zeros)
         return self.gtr.train_on_batch(x, 1.0, y, seed=2 * step + 1, sample0=sample0,
@@ -120,7 +120,7 @@ def run_step(models, x, step, sample0):
         if name == "DeltaP":
             m.forward(x)
         else:
-            m.forward(x, seed=step, sample0=sample0)
+            m.forward(x, seed=step, sample0=sample0, inference=True)      # predict: no backward follows
 
 
 def cpu_baseline(names, seconds_budget=20.0):

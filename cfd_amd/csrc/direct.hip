@@ -133,15 +133,102 @@ static int launch_conv_first(const float *x, const float *x2, int cin1, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv_first (3x3 stride 1, one input channel) + activation + MaxPooling2D(2,2) in one pass: the inference path of
+// DeltaP's g1 -> pool (DeltaP/models/generator.py:23-26).  The unfused pair writes the full-resolution activation
+// (B x H x W x 64: 537 MB in bf16 at B = 128) and reads it straight back to keep a quarter of it; here a thread
+// computes the four pre-activations under one pooled pixel, takes their maximum (LeakyReLU / ReLU / identity are
+// monotone, so act(max) == max(act), exactly) and writes one value.  Training keeps the unfused pair: the pool's
+// backward needs the full-resolution activation.
+// Tile = TXP pooled pixels of one pooled row; patch = 4 input rows x (2 TXP + 2) columns.
+// ---------------------------------------------------------------------------------------------
+constexpr int CONV_POOL_TX = 64;
+
+template <int CPT, typename TO>
+__global__ __launch_bounds__(256) void conv3_pool2_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, TO *__restrict__ y, int Hi,
+                                                          int Wi, int Cout, int act, float slope, int ntiles) {
+  constexpr int TX = CONV_POOL_TX;
+  constexpr int PW = 2 * TX + 2;
+  __shared__ float patch[4][PW];
+  const int tid = threadIdx.x;
+  const int CG = Cout / CPT;
+  const int cg = tid % CG, slot = tid / CG, pstep = 256 / CG;
+  const int Hp = Hi / 2, Wp = Wi / 2;
+  const int xtiles = (Wp + TX - 1) / TX;
+  const float ns = act_neg_scale(act, slope);
+  float wreg[CPT][9], breg[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wreg[c][k] = w[(size_t)(cg * CPT + c) * 9 + k];
+    breg[c] = bias ? bias[cg * CPT + c] : 0.f;
+  }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
+    const int xt = bid % xtiles; bid /= xtiles;
+    const int py = bid % Hp;
+    const int b = bid / Hp;
+    const int px0 = xt * TX;
+    const int iy0 = 2 * py - 1, ix0 = 2 * px0 - 1;
+    __syncthreads();
+    for (int e = tid; e < 4 * PW; e += 256) {
+      const int cx = e % PW, cy = e / PW;
+      const int iy = iy0 + cy, ix = ix0 + cx;
+      float v = 0.f;
+      if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) v = x[((size_t)b * Hi + iy) * Wi + ix];
+      patch[cy][cx] = v;
+    }
+    __syncthreads();
+    for (int px = slot; px < TX; px += pstep) {
+      if (px0 + px >= Wp) break;
+      float best[CPT];
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) best[c] = -3.402823466e38f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          float accv[CPT];
+#pragma unroll
+          for (int c = 0; c < CPT; ++c) accv[c] = breg[c];
+          // the same accumulation order as conv_first_kernel (kh, kw ascending): identical pre-activations
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const float v = patch[dy + kh][2 * px + dx + kw];
+#pragma unroll
+              for (int c = 0; c < CPT; ++c) accv[c] = fmaf(v, wreg[c][kh * 3 + kw], accv[c]);
+            }
+#pragma unroll
+          for (int c = 0; c < CPT; ++c) best[c] = accv[c] > best[c] ? accv[c] : best[c];
+        }
+      TO *dst = y + (((size_t)b * Hp + py) * Wp + px0 + px) * Cout + cg * CPT;
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) dst[c] = from_f32<TO>(apply_act_linear(best[c], ns));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // convT_out, step 1: taps[pixel][t] = sum_c x[pixel][c] * W[t][c]   (t = kh*4+kw), on MFMA.
 // One wave owns 16 pixels per iteration; the 16 x Cin weight matrix lives in registers.  Each lane
 // loads 32 contiguous bytes of its pixel per step so a wave-load covers whole 128-B lines; MFMA sums
 // over k in any order, so both operands simply use the same (permuted) k assignment.
 // ---------------------------------------------------------------------------------------------
+// `relu`: ReLU applied to x as it is loaded -- the inference path keeps ONE copy of the first encoder activation (the
+// LeakyReLU one, inside the concat buffer) and rectifies it here, ReLU(LeakyReLU(v)) == ReLU(v) (generator.py:38-40)
+__device__ __forceinline__ bf16x8 relu8(bf16x8 v) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 b = __builtin_bit_cast(s16x8, v);
+  b = b & ~(b >> 15);                 // negative (sign bit set, -0 and NaN with sign included) -> +0
+  return __builtin_bit_cast(bf16x8, b);
+}
+
 template <int CIN>
 __global__ __launch_bounds__(256) void tapgemm_bf16_kernel(const bf16 *__restrict__ x, int ldx,
                                                           const bf16 *__restrict__ w, float *__restrict__ taps,
-                                                          int npix) {
+                                                          int npix, int relu) {
   constexpr int STEPS = CIN / 64;  // each step: 64 channels = 2 MFMA k-steps of 32
   const int lane = threadIdx.x & 63;
   const int fr = lane & 15, fq = lane >> 4;
@@ -163,6 +250,7 @@ __global__ __launch_bounds__(256) void tapgemm_bf16_kernel(const bf16 *__restric
     for (int s = 0; s < STEPS; ++s) {
       xa[s][0] = *(const bf16x8 *)(xp + s * 64);
       xa[s][1] = *(const bf16x8 *)(xp + s * 64 + 8);
+      if (relu) { xa[s][0] = relu8(xa[s][0]); xa[s][1] = relu8(xa[s][1]); }
     }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
@@ -176,7 +264,7 @@ __global__ __launch_bounds__(256) void tapgemm_bf16_kernel(const bf16 *__restric
 template <int CIN>
 __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const float *__restrict__ x, int ldx,
                                                          const float *__restrict__ w, float *__restrict__ taps,
-                                                         int npix) {
+                                                         int npix, int relu) {
   constexpr int STEPS = CIN / 32;  // each step: 32 channels: lane group fq supplies k = 32 s + 8 fq + e
   const int lane = threadIdx.x & 63;
   const int fr = lane & 15, fq = lane >> 4;
@@ -195,8 +283,12 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const float *__restric
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      const f32x4 a0 = *(const f32x4 *)(xp + s * 32);
-      const f32x4 a1 = *(const f32x4 *)(xp + s * 32 + 4);
+      f32x4 a0 = *(const f32x4 *)(xp + s * 32);
+      f32x4 a1 = *(const f32x4 *)(xp + s * 32 + 4);
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[e] = a0[e] > 0.f ? a0[e] : 0.f; a1[e] = a1[e] > 0.f ? a1[e] : 0.f; }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][0][e], a0[e], acc, 0, 0, 0);
 #pragma unroll
@@ -308,9 +400,39 @@ extern "C" int cfd_conv_first(const float *x, const float *x2, int cin1, int cin
   CFD_FAIL(CFD_EUNSUPPORTED, "conv_first: k=%d s=%d cin=%d not built", ksize, stride, cin);
 }
 
+extern "C" int cfd_conv3_pool2(const float *x, const float *w, const float *bias, void *y, int B, int Hi, int Wi,
+                               int Cout, int act, float leaky_slope, int out_dtype, void *stream) {
+  CFD_REQUIRE(x && w && y, "NULL pointer");
+  CFD_REQUIRE(out_dtype == CFD_BF16 || out_dtype == CFD_F32, "bad out_dtype");
+  CFD_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Hi % 2 == 0 && Wi % 2 == 0, "bad shape (H and W must be even)");
+  CFD_REQUIRE(act == CFD_ACT_NONE || act == CFD_ACT_LEAKY || act == CFD_ACT_RELU, "activation must be monotone");
+  CFD_REQUIRE(act != CFD_ACT_LEAKY || leaky_slope >= 0.f, "a negative LeakyReLU slope is not monotone");
+  constexpr int CPT = 8;
+  const int CG = Cout / CPT;
+  CFD_REQUIRE(Cout % CPT == 0 && CG <= 256 && 256 % CG == 0, "conv3_pool2: Cout=%d unsupported", Cout);
+  const int64_t nt64 = (int64_t)B * (Hi / 2) * (((Wi / 2) + CONV_POOL_TX - 1) / CONV_POOL_TX);
+  CFD_REQUIRE(nt64 < (1LL << 31), "too many tiles");
+  const int ntiles = (int)nt64, blocks = ntiles < 2048 ? ntiles : 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == CFD_BF16)
+    hipLaunchKernelGGL((conv3_pool2_kernel<CPT, bf16>), dim3(blocks), dim3(256), 0, st, x, w, bias, (bf16 *)y, Hi, Wi,
+                       Cout, act, leaky_slope, ntiles);
+  else
+    hipLaunchKernelGGL((conv3_pool2_kernel<CPT, float>), dim3(blocks), dim3(256), 0, st, x, w, bias, (float *)y, Hi, Wi,
+                       Cout, act, leaky_slope, ntiles);
+  CFD_LAUNCH_CHECK();
+  return CFD_OK;
+}
+
 extern "C" int cfd_convT_out(const void *x, int ldx, const void *w, const float *bias, float *taps, float *y,
                              float *logits, int B, int Hi, int Wi, int Cin, int dtype, int apply_sigmoid,
                              void *stream) {
+  return cfd_convT_out_relu(x, ldx, w, bias, taps, y, logits, B, Hi, Wi, Cin, dtype, apply_sigmoid, 0, stream);
+}
+
+extern "C" int cfd_convT_out_relu(const void *x, int ldx, const void *w, const float *bias, float *taps, float *y,
+                                  float *logits, int B, int Hi, int Wi, int Cin, int dtype, int apply_sigmoid,
+                                  int relu_on_load, void *stream) {
   CFD_REQUIRE(x && w && taps && y, "NULL pointer");
   CFD_REQUIRE(dtype == CFD_BF16 || dtype == CFD_F32, "bad dtype");
   CFD_REQUIRE(ldx >= Cin && ldx % (dtype == CFD_BF16 ? 8 : 4) == 0, "bad ldx=%d", ldx);
@@ -325,10 +447,10 @@ extern "C" int cfd_convT_out(const void *x, int ldx, const void *w, const float 
   if (Cin == C) {                                                                                               \
     if (dtype == CFD_BF16)                                                                                      \
       hipLaunchKernelGGL(tapgemm_bf16_kernel<C>, dim3(blocks), dim3(256), 0, st, (const bf16 *)x, ldx,          \
-                         (const bf16 *)w, taps, npix);                                                          \
+                         (const bf16 *)w, taps, npix, relu_on_load);                                            \
     else                                                                                                        \
       hipLaunchKernelGGL(tapgemm_f32_kernel<C>, dim3(blocks), dim3(256), 0, st, (const float *)x, ldx,          \
-                         (const float *)w, taps, npix);                                                         \
+                         (const float *)w, taps, npix, relu_on_load);                                           \
   } else
   TAPGEMM(512) TAPGEMM(256) TAPGEMM(128) TAPGEMM(64) { CFD_FAIL(CFD_EUNSUPPORTED, "convT_out: Cin=%d not built", Cin); }
 #undef TAPGEMM

@@ -197,14 +197,15 @@ class GeneratorModel(Model):
             g = self._graphs.get(B)
             if g is None:
                 # bit 59 of the seed -> bit 63 of every layer's drop_seed (seed * 16 + layer): epoch-keyed
-                g = self._graphs[B] = _GraphedForward(self.net, xd, seed=(1 << 59) | (self._next_seed() & ((1 << 59) - 1)))
+                g = self._graphs[B] = _GraphedForward(self.net, xd, inference=True,
+                                                      seed=(1 << 59) | (self._next_seed() & ((1 << 59) - 1)))
             return g(xd).cpu().numpy()
-        return _forward_chunked(self.net.forward, xd, True, seed=self._next_seed()).cpu().numpy()
+        return _forward_chunked(self.net.forward, xd, True, seed=self._next_seed(), inference=True).cpu().numpy()
 
     def predict_on_device(self, x) -> torch.Tensor:
         """predict without the copy back to the host (not in Keras): the evaluation drivers feed the result to
         ops.eval_metrics and fetch a few numbers per case instead of the fields"""
-        return _forward_chunked(self.net.forward, _dev(x), True, seed=self._next_seed())
+        return _forward_chunked(self.net.forward, _dev(x), True, seed=self._next_seed(), inference=True)
 
     __call__ = predict
 

@@ -239,9 +239,27 @@ def conv_first(x: torch.Tensor, x2: Optional[torch.Tensor], w: torch.Tensor, bia
     return out
 
 
+def conv3_pool2(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], cout: int, act: int,
+                out_dtype: torch.dtype, out: Optional[torch.Tensor] = None, slope: float = LEAKY_SLOPE) -> torch.Tensor:
+    """Conv2D 3x3 'same' on a 1-channel fp32 image + activation + MaxPooling2D(2,2), fused (inference)."""
+    B, Hi, Wi, c1 = x.shape
+    _need(c1 == 1 and x.is_contiguous() and x.dtype == torch.float32, "conv3_pool2: dense fp32 (B,H,W,1) input")
+    _need(Hi % 2 == 0 and Wi % 2 == 0, "conv3_pool2 needs even H and W")
+    want = (B, Hi // 2, Wi // 2, cout)
+    if out is None:
+        out = torch.empty(want, dtype=out_dtype, device=x.device)
+    _need(tuple(out.shape) == want and out.is_contiguous(), f"conv3_pool2 out is {tuple(out.shape)}, expected dense {want}")
+    _numel(w, cout * 9, "conv3_pool2 weight", torch.float32)
+    _numel(bias, cout, "conv3_pool2 bias", torch.float32)
+    check(_lib.load().cfd_conv3_pool2(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), B, Hi, Wi, cout, act, slope,
+                                      _DT[out.dtype], _stream()), "cfd_conv3_pool2")
+    return out
+
+
 def convT_out(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], apply_sigmoid: bool = True,
-              want_logits: bool = False):
-    """Conv2DTranspose(1,(4,4),s2,'same') [+ sigmoid]; returns fp32 (B,2H,2W,1) (and the logits)."""
+              want_logits: bool = False, relu_on_load: bool = False):
+    """Conv2DTranspose(1,(4,4),s2,'same') [+ sigmoid]; returns fp32 (B,2H,2W,1) (and the logits).
+    relu_on_load: ReLU applied to x while it is read (the inference path's single copy of the e1 skip)."""
     B, Hi, Wi, cin = x.shape
     xp, ldx = _nhwc(x)
     taps = _workspace(B * Hi * Wi * 16 * 4, x.device)
@@ -249,8 +267,8 @@ def convT_out(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], ap
     logits = torch.empty_like(y) if want_logits else None
     _numel(w, 16 * cin, "convT_out weight", x.dtype)
     _numel(bias, 1, "convT_out bias", torch.float32)
-    check(_lib.load().cfd_convT_out(xp, ldx, _ptr(w), _ptr(bias), _ptr(taps), _ptr(y), _ptr(logits), B, Hi, Wi, cin,
-                                    _DT[x.dtype], int(apply_sigmoid), _stream()), "cfd_convT_out")
+    check(_lib.load().cfd_convT_out_relu(xp, ldx, _ptr(w), _ptr(bias), _ptr(taps), _ptr(y), _ptr(logits), B, Hi, Wi, cin,
+                                         _DT[x.dtype], int(apply_sigmoid), int(relu_on_load), _stream()), "cfd_convT_out")
     return (y, logits) if want_logits else y
 
 

@@ -123,6 +123,20 @@ int cfd_conv_first(const float *x, const float *x2, int cin1, int cin2, const fl
 int cfd_convT_out(const void *x, int ldx, const void *w, const float *bias, float *taps, float *y, float *logits,
                   int B, int Hi, int Wi, int Cin, int dtype, int apply_sigmoid, void *stream);
 
+/* The same with ReLU applied to x as it is loaded (relu_on_load != 0): the inference path keeps one copy of the first
+ * encoder activation -- the LeakyReLU one, written straight into the concat buffer -- and the Concatenate -> ReLU of
+ * generator.py:38-40 happens here, ReLU(LeakyReLU(v)) == ReLU(v). */
+int cfd_convT_out_relu(const void *x, int ldx, const void *w, const float *bias, float *taps, float *y, float *logits,
+                       int B, int Hi, int Wi, int Cin, int dtype, int apply_sigmoid, int relu_on_load, void *stream);
+
+/* Conv2D 3x3 'same' on ONE input channel + bias + activation + MaxPooling2D(2,2) in one pass (inference path of
+ * DeltaP/models/generator.py:23-26: g1 -> LeakyReLU -> pool).  x fp32 [B][Hi][Wi][1]; w fp32 packed [Cout][3][3][1];
+ * y `out_dtype` dense [B][Hi/2][Wi/2][Cout].  act must be monotone (NONE / LEAKY with slope >= 0 / RELU): the maximum is
+ * taken over the four pre-activations, which equals pooling the activations exactly.  The full-resolution activation
+ * is never written (training keeps cfd_conv_first + cfd_maxpool2: the pool's backward needs it). */
+int cfd_conv3_pool2(const float *x, const float *w, const float *bias, void *y, int B, int Hi, int Wi, int Cout, int act,
+                    float leaky_slope, int out_dtype, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Fused bandwidth-bound ops.
  * ---------------------------------------------------------------------------------- */

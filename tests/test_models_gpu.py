@@ -153,3 +153,28 @@ def test_shape_mismatches_are_refused_on_the_host():
     with pytest.raises(_lib.CfdError):
         ops.field_loss(small, big, ops.MAE, torch.zeros(1, device="cuda"))
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_inference_paths_equal_training_forward(dtype):
+    """predict-only paths that skip intermediate tensors give the SAME values as the forward a backward can follow:
+    generator with the first encoder activation written once (LeakyReLU copy, rectified on load by the output layer),
+    DeltaP CNN with g1 + LeakyReLU + max-pool fused (max over pre-activations of a monotone activation)."""
+    from cfd_amd import nets, synthetic
+    x, _, _ = synthetic.model_batch([0, 1, 2])
+    xd = torch.from_numpy(x).cuda()
+    for arch in ("U", "P"):
+        g = nets.Generator(arch, dtype=dtype, seed=3)
+        a = g.forward(xd, seed=5).clone()
+        b = g.forward(xd, seed=5, inference=True).clone()
+        # same kernels and operand values; only the fp32 atomics of the BatchNorm statistics commit in another order
+        # (fp32: 1e-6-level; bf16: that noise flips the rounding of single activations, as between two runs of one path)
+        tol = 2e-5 if dtype == torch.float32 else 1e-2
+        assert float((a - b).abs().max()) <= tol * float(a.abs().max())
+    c = nets.CnnRegressor(dtype=dtype, seed=4)
+    pt = c.forward(xd, training=True, drop_mask=torch.ones((3, 256), dtype=torch.uint8, device="cuda")).clone()
+    pl = c.plan(3)
+    g2_train = pl["g2"].clone()
+    pi = c.forward(xd, training=False).clone()
+    assert torch.equal(pl["g2i"], g2_train)            # the pooled activation, bit for bit
+    assert pi.shape == pt.shape and torch.isfinite(pi).all()
