@@ -46,6 +46,98 @@ GEN_ARCH = {"U": U_GEN, "P": P_GEN}
 DISC = [(128, 2, False), (256, 2, True), (512, 2, True), (1024, 2, True), (1024, 1, True)]
 
 
+# --------------------------------------------------------------------------------------
+# bf16 emulation (parity tests of the bf16 HIP path at STEP level)
+# --------------------------------------------------------------------------------------
+# The HIP path in bf16 mode keeps activations, inter-layer gradients and the MFMA weight operands in bf16 (fp32
+# accumulation, fp32 master weights / statistics / losses).  Against the plain fp32 oracle a whole training step can
+# only be compared loosely, and nothing separates "bf16 quantisation" from "kernel error".  Inside `bf16_emulation()`
+# this oracle rounds to bf16 at the same points the HIP path stores bf16 -- after every activation, on the pre-BatchNorm
+# conv output of the layers above RAW_F32_MAX_ELEMS per sample, on every weight that feeds an MFMA (not e1 / c1 / g1:
+# the direct first-layer kernels read the fp32 master), and on the gradients flowing back through those points -- so
+# what is left between the two is accumulation order and the single activations whose rounding flips.
+# `noise` > 0 is a PROBE, not a model of anything: every stored activation is multiplied by (1 + noise * N(0,1)) before it
+# is rounded, i.e. perturbed by a fraction of one bf16 ulp (2^-8 relative).  The change this makes to the oracle's OWN
+# gradients measures how strongly the network amplifies single rounding flips (BatchNorm over 8-32 pixels in the
+# deepest layers, ReLU / dropout kinks); the tests require the HIP path to sit inside that band.
+_EMU = {"on": False, "raw_f32_max": 524288, "noise": 0.0}
+
+
+class _RoundBoth(torch.autograd.Function):
+    """value -> bf16 -> fp32 in the forward, the same on the gradient in the backward (a tensor stored in bf16 whose
+    gradient is stored in bf16 too)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        if _EMU["noise"]:
+            gen = torch.Generator().manual_seed(x.numel() % 1000003)
+            x = x * (1.0 + _EMU["noise"] * torch.randn(x.shape, generator=gen))
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """bf16 operand copy of an fp32 master weight: rounded in the forward, gradient passed through in fp32"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """fp32 value whose GRADIENT is stored in bf16 (the pre-BatchNorm output of a small layer: kept in fp32, but the
+    BatchNorm backward writes d(raw) in the compute dtype, and the weight / data gradient GEMMs read it as bf16)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def R(x: torch.Tensor) -> torch.Tensor:
+    return _RoundBoth.apply(x) if _EMU["on"] else x
+
+
+def RW(w: torch.Tensor) -> torch.Tensor:
+    return _RoundFwd.apply(w) if _EMU["on"] else w
+
+
+def RPRE(x: torch.Tensor) -> torch.Tensor:
+    """pre-activation of a layer without BatchNorm: never stored in the forward, its gradient is stored in bf16"""
+    return _RoundBwd.apply(x) if _EMU["on"] else x
+
+
+def RRAW(x: torch.Tensor) -> torch.Tensor:
+    """pre-BatchNorm conv output: bf16 only above the HIP path's threshold (cfd_amd.nets.RAW_F32_MAX_ELEMS)"""
+    if not _EMU["on"]:
+        return x
+    if x.shape[1] * x.shape[2] * x.shape[3] > _EMU["raw_f32_max"]:
+        return _RoundBoth.apply(x)
+    return _RoundBwd.apply(x)
+
+
+class bf16_emulation:
+    def __init__(self, raw_f32_max: int = 524288, noise: float = 0.0):
+        self.raw, self.noise = raw_f32_max, noise
+
+    def __enter__(self):
+        self.prev = dict(_EMU)
+        _EMU.update(on=True, raw_f32_max=self.raw, noise=self.noise)
+
+    def __exit__(self, *a):
+        _EMU.update(self.prev)
+
+
 def _t(x) -> torch.Tensor:
     if isinstance(x, np.ndarray):
         x = torch.from_numpy(np.ascontiguousarray(x))
@@ -211,27 +303,26 @@ def generator_forward(p: Params, x, arch: str, dropout_masks: Sequence, per_samp
     skips = []
     g = x
     for i, _f in enumerate(a["enc"], 1):
-        g = conv2d_same(g, p[f"e{i}.kernel"], p[f"e{i}.bias"], 2)
-        if i > 1:
-            g = batchnorm(g, p, f"e{i}", True, per_sample_bn)
-        g = leaky(g)
+        g = conv2d_same(g, p[f"e{i}.kernel"] if i == 1 else RW(p[f"e{i}.kernel"]), p[f"e{i}.bias"], 2)
+        g = batchnorm(RRAW(g), p, f"e{i}", True, per_sample_bn) if i > 1 else RPRE(g)
+        g = R(leaky(g))
         skips.append(g)
         if acts is not None:
             acts[f"e{i}"] = g
-    g = torch.relu(conv2d_same(g, p["b.kernel"], p["b.bias"], 2))
+    g = R(torch.relu(RPRE(conv2d_same(g, RW(p["b.kernel"]), p["b.bias"], 2))))
     if acts is not None:
         acts["b"] = g
     mi = 0
     for i, (_f, drop) in enumerate(a["dec"], 1):
-        g = conv2d_transpose_same(g, p[f"d{i}.kernel"], p[f"d{i}.bias"])
-        g = batchnorm(g, p, f"d{i}", True, per_sample_bn)
+        g = conv2d_transpose_same(g, RW(p[f"d{i}.kernel"]), p[f"d{i}.bias"])
+        g = batchnorm(RRAW(g), p, f"d{i}", True, per_sample_bn)
         if drop:
             g = g * masks[mi] * KS.DROPOUT_KEEP_SCALE
             mi += 1
-        g = torch.relu(torch.cat([g, skips[-i]], dim=-1))  # ReLU after concat: also rectifies the skip
+        g = R(torch.relu(torch.cat([g, skips[-i]], dim=-1)))  # ReLU after concat: also rectifies the skip
         if acts is not None:
             acts[f"d{i}"] = g
-    logits = conv2d_transpose_same(g, p["out.kernel"], p["out.bias"])
+    logits = conv2d_transpose_same(g, RW(p["out.kernel"]), p["out.bias"])
     return logits if return_logits else torch.sigmoid(logits)
 
 
@@ -240,11 +331,10 @@ def discriminator_forward(p: Params, src, tgt, training: bool, per_sample_bn: bo
     """define_discriminator (U/models/discriminator.py:12-44).  BN uses the default training flag."""
     d = torch.cat([_t(src), _t(tgt)], dim=-1)
     for i, (_f, s, bn) in enumerate(DISC, 1):
-        d = conv2d_same(d, p[f"c{i}.kernel"], p[f"c{i}.bias"], s)
-        if bn:
-            d = batchnorm(d, p, f"c{i}", training, per_sample_bn, stats_out)
-        d = leaky(d)
-    logits = conv2d_same(d, p["c6.kernel"], p["c6.bias"], 1)
+        d = conv2d_same(d, p[f"c{i}.kernel"] if i == 1 else RW(p[f"c{i}.kernel"]), p[f"c{i}.bias"], s)
+        d = batchnorm(RRAW(d), p, f"c{i}", training, per_sample_bn, stats_out) if bn else RPRE(d)
+        d = R(leaky(d))
+    logits = conv2d_same(d, RW(p["c6.kernel"]), p["c6.bias"], 1)
     return logits if return_logits else torch.sigmoid(logits)
 
 
@@ -252,19 +342,19 @@ def cnn_forward(p: Params, x, dropout_mask=None):
     """define_cnn_model (DeltaP/models/generator.py:15-49).  Dropout is a normal layer:
     active (mask given) in train_on_batch, identity in predict/test_on_batch."""
     g = _t(x)
-    g = leaky(conv2d_same(g, p["g1.kernel"], p["g1.bias"], 1))
+    g = R(leaky(RPRE(conv2d_same(g, p["g1.kernel"], p["g1.bias"], 1))))
     g = F.max_pool2d(g.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
-    g = leaky(torch.relu(conv2d_same(g, p["g3.kernel"], p["g3.bias"], 1)))  # LeakyReLU after relu: no-op
-    g = torch.relu(conv2d_same(g, p["g4.kernel"], p["g4.bias"], 1))
+    g = R(leaky(torch.relu(RPRE(conv2d_same(g, RW(p["g3.kernel"]), p["g3.bias"], 1)))))  # LeakyReLU after relu: no-op
+    g = R(torch.relu(RPRE(conv2d_same(g, RW(p["g4.kernel"]), p["g4.bias"], 1))))
     g = F.max_pool2d(g.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
-    g = torch.relu(conv2d_same(g, p["g6.kernel"], p["g6.bias"], 1))
+    g = R(torch.relu(RPRE(conv2d_same(g, RW(p["g6.kernel"]), p["g6.bias"], 1))))
     g = F.max_pool2d(g.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
     g = g.reshape(g.shape[0], -1)  # Flatten in (H,W,C) order
-    g = torch.relu(g @ p["fc1.kernel"] + p["fc1.bias"])
+    g = R(torch.relu(RPRE(g @ RW(p["fc1.kernel"]) + p["fc1.bias"])))
     if dropout_mask is not None:
-        g = g * _t(dropout_mask) * KS.DROPOUT_KEEP_SCALE
-    g = torch.relu(g @ p["fc2.kernel"] + p["fc2.bias"])
-    return g @ p["fc3.kernel"] + p["fc3.bias"]
+        g = R(g * _t(dropout_mask) * KS.DROPOUT_KEEP_SCALE)
+    g = R(torch.relu(RPRE(g @ RW(p["fc2.kernel"]) + p["fc2.bias"])))
+    return g @ RW(p["fc3.kernel"]) + p["fc3.bias"]
 
 
 # --------------------------------------------------------------------------------------

@@ -58,6 +58,29 @@ def compare_grads(gk, ref_grads, prefix, tol, skip_bias_of_bn=True, report=None)
     return worst
 
 
+def compare_grads_bf16(gk, ref, probe, prefix, floor=2e-2):
+    """bf16 step: per-tensor rel-L2 of the HIP gradients against the bf16-EMULATED oracle (oracle.nets.bf16_emulation:
+    rounds where the HIP path stores bf16) must stay inside the band by which the emulated oracle's own gradients move
+    when every stored activation is perturbed by an eighth of a bf16 ulp (`probe`), plus `floor` (the north-star
+    bf16 tolerance).  That separates quantisation -- amplified by BatchNorm over 8-32 pixels and by ReLU / dropout kinks in
+    the deepest layers -- from kernel error: a wrong kernel would leave the band, rounding noise cannot."""
+    worst = (0.0, 0.0, "")
+    for k, g in ref.items():
+        if not k.startswith(prefix):
+            continue
+        name = k[len(prefix):]
+        mine, gr, gp = torch.from_numpy(gk[name]), g.detach(), probe[k].detach()
+        if gr.abs().max() < 1e-6 * max(1.0, float(mine.abs().max())) or \
+                (name.endswith(".bias") and (name[:-5] + ".bn.gamma") in gk):
+            assert float(mine.abs().max()) <= 1e-4, name
+            continue
+        e, band = rel_l2(mine, gr), rel_l2(gp, gr)
+        if e > worst[0]:
+            worst = (e, band, name)
+        assert e <= band + floor, f"{name}: rel L2 {e:.3e} outside the perturbation band {band:.3e} + {floor}"
+    return worst
+
+
 def check_adam_delta(mine, ref_after, ref_before, lr, keys, dtype):
     """the first Adam step is ~lr*sign(g) per element; compare the applied updates, tolerating the few
     elements whose near-zero gradient changes sign with the summation order"""
@@ -85,7 +108,15 @@ def test_d_train_on_batch(dtype, tol):
         loss_ref, gref = O.d_train_on_batch(po, opt, x, u, lab, return_grads=True)
         loss = tr.train_on_batch(torch.from_numpy(x).cuda(), torch.from_numpy(u).cuda(), label)
         if step == 0:
-            assert abs(loss - loss_ref) <= (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, abs(loss_ref))
+            assert abs(loss - loss_ref) <= (1e-4 if dtype == torch.float32 else 5e-3) * max(1.0, abs(loss_ref))
+            if dtype == torch.bfloat16:
+                refs = []
+                for noise in (0.0, 5e-4):
+                    with O.bf16_emulation(noise=noise):
+                        refs.append(O.d_train_on_batch(dict(w0), O.KerasAdam(2e-3, 0.5), x, u, lab, return_grads=True))
+                assert abs(loss - refs[0][0]) <= 2e-3 * max(1.0, abs(refs[0][0])), (loss, refs[0][0])
+                e, band, name = compare_grads_bf16(grads_keras(d), refs[0][1], refs[1][1], "")
+                print(f"D bf16 vs emulated oracle: loss {loss:.6f} vs {refs[0][0]:.6f}; worst grad {name} {e:.2e} (band {band:.2e})")
             rep = []
             w = compare_grads(grads_keras(d), gref, "", tol, report=rep)
             print(f"D step {step} {dtype}: loss {loss:.6f} vs {loss_ref:.6f}, worst grad rel-L2 {w:.3e}",
@@ -127,9 +158,19 @@ def test_gan_train_on_batch(arch, dtype, tol):
     ref, gref = O.gan_train_on_batch(pg, pd, opt, arch, x, lab, u, [m.float() for m in masks], return_grads=True)
     out = tr.train_on_batch(torch.from_numpy(x).cuda(), 1.0, torch.from_numpy(u).cuda(),
                             masks=[m.to(torch.uint8).cuda() for m in masks])
-    ltol = 1e-4 if dtype == torch.float32 else 3e-2
+    ltol = 1e-4 if dtype == torch.float32 else 5e-3       # north_star's bf16 bar is 2e-2; measured 1.6e-3
     for a, b in zip(out, ref):
         assert abs(a - b) <= ltol * max(1.0, abs(b)), (out, ref)
+    if dtype == torch.bfloat16:
+        refs = []
+        for noise in (0.0, 5e-4):
+            with O.bf16_emulation(noise=noise):
+                refs.append(O.gan_train_on_batch(dict(pg0), dict(pd0), O.KerasAdam(4e-4, 0.5), arch, x, lab, u,
+                                                 [m.float() for m in masks], return_grads=True))
+        for a, b in zip(out, refs[0][0]):
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (out, refs[0][0])
+        e, band, name = compare_grads_bf16(grads_keras(g), refs[0][1], refs[1][1], "g.")
+        print(f"GAN {arch} bf16 vs emulated oracle: losses {out} vs {refs[0][0]}; worst grad {name} {e:.2e} (band {band:.2e})")
     rep = []
     wg = compare_grads(grads_keras(g), gref, "g.", tol, report=rep)
     wd = compare_grads(grads_keras(d), {k: v for k, v in gref.items() if k.startswith("d.")}, "d.", tol)
@@ -164,7 +205,13 @@ def test_cnn_train_on_batch(dtype, tol):
     loss_ref, gref = O.cnn_train_on_batch(po, opt, x, y, mask.float(), return_grads=True)
     loss = tr.train_on_batch(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(),
                              drop_mask=mask.to(torch.uint8).cuda())
-    assert abs(loss - loss_ref) <= (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    assert abs(loss - loss_ref) <= (1e-4 if dtype == torch.float32 else 5e-3) * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    if dtype == torch.bfloat16:
+        with O.bf16_emulation():
+            l_emu, g_emu = O.cnn_train_on_batch(dict(po0), O.KerasAdam(1e-3, 0.5), x, y, mask.float(), return_grads=True)
+        assert abs(loss - l_emu) <= 1e-3 * max(1.0, abs(l_emu)), (loss, l_emu)
+        w_emu = compare_grads(grads_keras(c), g_emu, "", 2e-2)          # no BatchNorm here: the plain bar holds
+        print(f"CNN bf16 vs emulated oracle: loss {loss:.6f} vs {l_emu:.6f}; worst grad rel-L2 {w_emu:.2e}")
     rep = []
     w = compare_grads(grads_keras(c), gref, "", tol, report=rep)
     print(f"CNN {dtype}: loss {loss:.5f} vs {loss_ref:.5f}; worst grad rel-L2 {w:.3e}",
