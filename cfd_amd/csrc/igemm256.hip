@@ -69,6 +69,28 @@ __device__ __forceinline__ unsigned tap_mask(const int *g, int y0, int x0, int H
   return mv ? msk : 0u;
 }
 
+// walk over the taps of one class in table order (t = ky*kw + kx) by scalar increments; g = Igemm256Params::tgeo[cls]
+struct TapWalk {
+  int pix, wt;               // current tap: input-pixel offset dy*Wi + dx, weight tap index
+  int kx, kw;                // column in the tap grid, columns per row
+  int dpx, dpy, dwx, dwy;    // increments: next column / (next row, from the last column)
+  __device__ __forceinline__ void init(const int *g, int Wi, int t) {
+    kw = g[0];
+    const int dy0 = g[2], dys = g[3], dx0 = g[4], dxs = g[5], wt0 = g[6], wxs = g[7] & 0xffff, wys = g[7] >> 16;
+    const int ky = t / kw;
+    kx = t - ky * kw;
+    pix = (dy0 + dys * ky) * Wi + dx0 + dxs * kx;
+    wt = wt0 + wys * ky + wxs * kx;
+    dpx = dxs; dwx = wxs;
+    dpy = dys * Wi - (kw - 1) * dxs;
+    dwy = wys - (kw - 1) * wxs;
+  }
+  __device__ __forceinline__ void next() {
+    if (++kx == kw) { kx = 0; pix += dpy; wt += dwy; }
+    else { pix += dpx; wt += dwx; }
+  }
+};
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -172,11 +194,17 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   int iss_left = nkt;                       // K tiles not yet fully issued (incl. the current one)
   int iss_t = kbeg ? kbeg / p.cpt : 0, iss_c = kbeg - iss_t * p.cpt;
   unsigned s_a = 0, s_b = 0;                // scalar byte offsets: A = (wtap*Cin + c*64)*2, B = c*128
+  // A tap switch sits inside a memory cluster, i.e. on the critical path of its phase, and layers with few K tiles per
+  // tap (Cin 64..256) switch every 1..4 K tiles.  Looking the tap up in the kernel-argument table cost a dependent
+  // scalar load (a few hundred cycles, and its wait also drains the fragment reads sharing lgkmcnt) per switch; the
+  // taps of every kind form an affine grid (checked by the host), so the walk is a handful of scalar adds instead:
+  // tw_pix = (dy*Wi + dx) of the current tap, tw_wt = its weight tap index, (tw_kx) its column in the kh x kw grid.
+  TapWalk tw;
+  tw.init(P.tgeo[cls], p.Wi, iss_t);
   auto tap_switch = [&]() {
-    const int info = P.tapinfo[cls][iss_t];
-    s_a = (unsigned)(((info & 255) * p.Cin + iss_c * BKE) * ES);
+    s_a = (unsigned)((tw.wt * p.Cin + iss_c * BKE) * ES);
     s_b = (unsigned)(iss_c * 128);
-    const int tapx = (info >> 8) * p.ldx * ES;
+    const int tapx = tw.pix * p.ldx * ES;
 #pragma unroll
     for (int r = 0; r < 4; ++r) cur[r] = ((vmask[r] >> iss_t) & 1u) ? rowoff[r] + (unsigned)tapx : OOB;
   };
@@ -184,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
     if (iss_left > 1) {
       --iss_left;
       s_a += 128; s_b += 128;
-      if (++iss_c == p.cpt) { iss_c = 0; ++iss_t; tap_switch(); }
+      if (++iss_c == p.cpt) { iss_c = 0; ++iss_t; tw.next(); tap_switch(); }
     }
   };
   tap_switch();
@@ -860,11 +888,17 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
   int iss_left = nkt;
   int iss_t = kbeg ? kbeg / p.cpt : 0, iss_c = kbeg - iss_t * p.cpt;
   unsigned s_a = 0, s_b = 0;
+  // A tap switch sits inside a memory cluster, i.e. on the critical path of its phase, and layers with few K tiles per
+  // tap (Cin 64..256) switch every 1..4 K tiles.  Looking the tap up in the kernel-argument table cost a dependent
+  // scalar load (a few hundred cycles, and its wait also drains the fragment reads sharing lgkmcnt) per switch; the
+  // taps of every kind form an affine grid (checked by the host), so the walk is a handful of scalar adds instead:
+  // tw_pix = (dy*Wi + dx) of the current tap, tw_wt = its weight tap index, (tw_kx) its column in the kh x kw grid.
+  TapWalk tw;
+  tw.init(P.tgeo[cls], p.Wi, iss_t);
   auto tap_switch = [&]() {
-    const int info = P.tapinfo[cls][iss_t];
-    s_a = (unsigned)(((info & 255) * p.Cin + iss_c * BKE) * ES);
+    s_a = (unsigned)((tw.wt * p.Cin + iss_c * BKE) * ES);
     s_b = (unsigned)(iss_c * 128);
-    const int tapx = (info >> 8) * p.ldx * ES;
+    const int tapx = tw.pix * p.ldx * ES;
 #pragma unroll
     for (int r = 0; r < 4; ++r) cur[r] = ((vmask[r] >> iss_t) & 1u) ? rowoff[r] + (unsigned)tapx : OOB;
   };
@@ -872,7 +906,7 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
     if (iss_left > 1) {
       --iss_left;
       s_a += 128; s_b += 128;
-      if (++iss_c == p.cpt) { iss_c = 0; ++iss_t; tap_switch(); }
+      if (++iss_c == p.cpt) { iss_c = 0; ++iss_t; tw.next(); tap_switch(); }
     }
   };
   tap_switch();
@@ -1070,8 +1104,13 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
     g[0] = kw; g[1] = kh;
     g[2] = P.tapdy[cls][0]; g[3] = kh > 1 ? P.tapdy[cls][kw] - P.tapdy[cls][0] : 0;
     g[4] = P.tapdx[cls][0]; g[5] = kw > 1 ? P.tapdx[cls][1] - P.tapdx[cls][0] : 0;
+    const int wt0 = P.tapinfo[cls][0] & 255;
+    const int wxs = kw > 1 ? (P.tapinfo[cls][1] & 255) - wt0 : 0, wys = kh > 1 ? (P.tapinfo[cls][kw] & 255) - wt0 : 0;
+    g[6] = wt0; g[7] = (wys << 16) | (wxs & 0xffff);
+    CFD_REQUIRE(wxs >= 0 && wys >= 0 && wxs < 256 && wys < 256, "weight taps of kind %d do not ascend", p.kind);
     for (int t = 0; t < p.ntaps; ++t)
-      CFD_REQUIRE(kh * kw == p.ntaps && P.tapdy[cls][t] == g[2] + g[3] * (t / kw) && P.tapdx[cls][t] == g[4] + g[5] * (t % kw),
+      CFD_REQUIRE(kh * kw == p.ntaps && P.tapdy[cls][t] == g[2] + g[3] * (t / kw) && P.tapdx[cls][t] == g[4] + g[5] * (t % kw) &&
+                      (P.tapinfo[cls][t] & 255) == wt0 + wys * (t / kw) + wxs * (t % kw),
                   "taps of kind %d are not an affine grid", p.kind);
   }
   // staged bf16 output: whole-tile kernel only (n tile 256), no split-K, 16-B aligned rows
