@@ -52,7 +52,7 @@ struct RsLayout {
   int64_t total;        // points of all cases
   int64_t wall_stride;  // doubles per case in the wall block: [S] lo, [S] hi, [W] ylo, [W] yhi, 2 status
   // byte offsets from the workspace base
-  int64_t o_wall, o_sacc, o_scnt, o_bbox, o_grid, o_bnd, o_start, o_cnt, o_cell, o_syz, o_sidx, bytes;
+  int64_t o_wall, o_sacc, o_scnt, o_bbox, o_grid, o_start, o_cnt, o_cell, o_syz, o_spu, o_sidx, bytes;
 };
 
 static inline int64_t align16(int64_t v) { return (v + 15) & ~(int64_t)15; }
@@ -67,12 +67,12 @@ static RsLayout rs_layout(int ncase, int W, int S, int64_t total) {
   L.o_sacc = o;  o = align16(o + (int64_t)ncase * 4 * S * 8);            // uint64 [ncase][4][S]: mn1 mx1 mn2 mx2
   L.o_scnt = o;  o = align16(o + (int64_t)ncase * 4 * S * 4);            // int    [ncase][4][S]: n1 n2 nan1 nan2
   L.o_bbox = o;  o = align16(o + (int64_t)ncase * 4 * 8);                // uint64 [ncase][4]: ymin ymax zmin zmax
-  L.o_grid = o;  o = align16(o + (int64_t)ncase * 8 * 8);                // double [ncase][8]: ny nz y0 z0 invy invz - -
-  L.o_bnd = o;   o = align16(o + (cells + 3 * (int64_t)ncase) * 8);      // double boundaries, per case ny+1 + nz+1
+  L.o_grid = o;  o = align16(o + (int64_t)ncase * 8 * 8);                // double [ncase][8]: ny nz y0 z0 1/hy 1/hz hy hz
   L.o_start = o; o = align16(o + (cells + (int64_t)ncase) * 4);          // int cell_start, per case ncell+1
   L.o_cnt = o;   o = align16(o + cells * 4);                             // int cell count / fill
   L.o_cell = o;  o = align16(o + total * 4);                             // int cell id of every point
   L.o_syz = o;   o = align16(o + total * 16);                            // double2 (y,z) sorted by cell
+  L.o_spu = o;   o = align16(o + total * 16);                            // double2 (p,U) in the same order
   L.o_sidx = o;  o = align16(o + total * 4);                             // int original index (within the case), sorted
   L.bytes = o;
   return L;
@@ -214,13 +214,11 @@ __global__ __launch_bounds__(256) void case_setup_kernel(const int64_t *__restri
                                                         const int *__restrict__ scnt,
                                                         const unsigned long long *__restrict__ bbox,
                                                         double *__restrict__ wall, int64_t wall_stride,
-                                                        double *__restrict__ grid, double *__restrict__ bnd,
+                                                        double *__restrict__ grid,
                                                         double pts_per_cell) {
   extern __shared__ double sm[];  // [3][S]: xp, lo, hi
   double *xp = sm, *lo = sm + S, *hi = sm + 2 * S;
   __shared__ int nvalid;
-  __shared__ int g_ny, g_nz;
-  __shared__ double g_y0, g_z0, g_hy, g_hz;
   const int cs = blockIdx.x;
   double *w = wall + (int64_t)cs * wall_stride;
   const unsigned long long *a = sacc + (int64_t)cs * 4 * S;
@@ -267,12 +265,11 @@ __global__ __launch_bounds__(256) void case_setup_kernel(const int64_t *__restri
       nz = (int64_t)target < cap ? (int64_t)target : cap;
     }
     while (ny * nz > cap) { if (ny >= nz) ny = (ny + 1) / 2; else nz = (nz + 1) / 2; }
-    g_ny = (int)ny; g_nz = (int)nz;
-    g_y0 = any ? ymn : 0.0; g_z0 = any ? zmn : 0.0;
-    g_hy = ry > 0.0 ? ry / (double)ny : 1.0;
-    g_hz = rz > 0.0 ? rz / (double)nz : 1.0;
+    const double g_y0 = any ? ymn : 0.0, g_z0 = any ? zmn : 0.0;
+    const double g_hy = ry > 0.0 ? ry / (double)ny : 1.0, g_hz = rz > 0.0 ? rz / (double)nz : 1.0;
     double *gp = grid + (int64_t)cs * 8;
     gp[0] = (double)ny; gp[1] = (double)nz; gp[2] = g_y0; gp[3] = g_z0; gp[4] = 1.0 / g_hy; gp[5] = 1.0 / g_hz;
+    gp[6] = g_hy; gp[7] = g_hz;
   }
   __syncthreads();
   const int n = nvalid;
@@ -282,50 +279,49 @@ __global__ __launch_bounds__(256) void case_setup_kernel(const int64_t *__restri
     w[2 * S + j] = l;
     w[2 * S + W + j] = h;
   }
-  // cell boundaries: by[k] = y0 + k*hy (k = 0..ny), bz[k] likewise; only their ORDER matters for correctness
-  const int64_t beg = offs[cs];
-  double *by = bnd + cell_base(cs, beg) + 3 * (int64_t)cs, *bz = by + g_ny + 1;
-  for (int k = threadIdx.x; k <= g_ny; k += 256) by[k] = g_y0 + (double)k * g_hy;
-  for (int k = threadIdx.x; k <= g_nz; k += 256) bz[k] = g_z0 + (double)k * g_hz;
+  // (cell boundary k of an axis is y0 + k*hy, evaluated where needed: cell_bound(); only their ORDER matters)
 }
 
 // cell of coordinate v along one axis: cell k holds b[k] <= v < b[k+1]; cells 0 and n-1 are open-ended.
 // The guess only saves steps; the two loops make the result agree with the boundary table exactly, which is what
 // the search's stop test relies on.  NaN -> cell 0.
-__device__ __forceinline__ int bin1(double v, double o, double inv, const double *__restrict__ b, int n) {
+// boundary k of an axis: ONE expression everywhere (binning of the points, of the pixels, and the stop test), each
+// operation rounded once (-ffp-contract=off), so every kernel sees the same doubles without a boundary table in memory
+// (the table cost two or three dependent loads per axis per pixel, and the kernel is a chain of load latencies)
+__device__ __forceinline__ double cell_bound(double o, double h, int k) { return o + (double)k * h; }
+
+__device__ __forceinline__ int bin1(double v, double o, double inv, double h, int n) {
   const double t = (v - o) * inv;
   int k = (t >= 0.0) ? (t < (double)(n - 1) ? (int)t : n - 1) : 0;
-  while (k + 1 < n && v >= b[k + 1]) ++k;
-  while (k > 0 && v < b[k]) --k;
+  while (k + 1 < n && v >= cell_bound(o, h, k + 1)) ++k;
+  while (k > 0 && v < cell_bound(o, h, k)) --k;
   return k;
 }
 
 struct CaseGrid {
   int ny, nz;
-  double y0, z0, invy, invz;
-  const double *by, *bz;
+  double y0, z0, invy, invz, hy, hz;
+  __device__ __forceinline__ double by(int k) const { return cell_bound(y0, hy, k); }
+  __device__ __forceinline__ double bz(int k) const { return cell_bound(z0, hz, k); }
 };
-__device__ __forceinline__ CaseGrid load_grid(const double *__restrict__ grid, const double *__restrict__ bnd, int cs,
-                                              int64_t beg) {
-  const double *gp = grid + (int64_t)cs * 8;
+__device__ __forceinline__ CaseGrid load_grid(const double *__restrict__ grid, int cs) {
+  const double *gp = grid + (int64_t)cs * 8;     // one 64-B record per case
   CaseGrid G;
-  G.ny = (int)gp[0]; G.nz = (int)gp[1]; G.y0 = gp[2]; G.z0 = gp[3]; G.invy = gp[4]; G.invz = gp[5];
-  G.by = bnd + cell_base(cs, beg) + 3 * (int64_t)cs;
-  G.bz = G.by + G.ny + 1;
+  G.ny = (int)gp[0]; G.nz = (int)gp[1]; G.y0 = gp[2]; G.z0 = gp[3]; G.invy = gp[4]; G.invz = gp[5]; G.hy = gp[6]; G.hz = gp[7];
   return G;
 }
 
 __global__ __launch_bounds__(256) void bin_count_kernel(const double *__restrict__ pts, const int64_t *__restrict__ offs,
                                                        int ncase, int64_t total, const double *__restrict__ grid,
-                                                       const double *__restrict__ bnd, int *__restrict__ cnt,
+                                                       int *__restrict__ cnt,
                                                        int *__restrict__ cell) {
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= total) return;
   const int cs = case_of(offs, ncase, g);
   const int64_t beg = offs[cs];
-  const CaseGrid G = load_grid(grid, bnd, cs, beg);
-  const int cy = bin1(pts[g * 5 + 1], G.y0, G.invy, G.by, G.ny);
-  const int cz = bin1(pts[g * 5 + 2], G.z0, G.invz, G.bz, G.nz);
+  const CaseGrid G = load_grid(grid, cs);
+  const int cy = bin1(pts[g * 5 + 1], G.y0, G.invy, G.hy, G.ny);
+  const int cz = bin1(pts[g * 5 + 2], G.z0, G.invz, G.hz, G.nz);
   const int c = cy * G.nz + cz;
   cell[g] = c;
   atomicAdd(cnt + cell_base(cs, beg) + c, 1);
@@ -367,7 +363,8 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(const int64_t *__restrict
 __global__ __launch_bounds__(256) void bin_scatter_kernel(const double *__restrict__ pts, const int64_t *__restrict__ offs,
                                                          int ncase, int64_t total, const int *__restrict__ cell,
                                                          const int *__restrict__ start, int *__restrict__ cnt,
-                                                         double2 *__restrict__ syz, int *__restrict__ sidx) {
+                                                         double2 *__restrict__ syz, double2 *__restrict__ spu,
+                                                         int *__restrict__ sidx) {
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= total) return;
   const int cs = case_of(offs, ncase, g);
@@ -375,20 +372,82 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const double *__restri
   const int c = cell[g];
   const int pos = start[cell_base(cs, beg) + cs + c] + atomicAdd(cnt + cell_base(cs, beg) + c, 1);
   syz[beg + pos] = make_double2(pts[g * 5 + 1], pts[g * 5 + 2]);
+  spu[beg + pos] = make_double2(pts[g * 5 + 3], pts[g * 5 + 4]);
   sidx[beg + pos] = (int)(g - beg);
 }
 
-constexpr int TILE_H = 8, TILE_W = 32;   // pixels per block: 8 rows x 32 columns (one wave = 2 rows)
+constexpr int TILE_H = 8, TILE_W = 32;   // pixels per block: 8 rows x 32 columns; one wave = 8 rows x 8 columns
+constexpr int WIN_CAP = 128;             // points a wave stages in LDS for its 64 pixels
+constexpr int WIN_ROWS = 8;              // cell rows of a wave's window at most (else the general search)
 
-__global__ __launch_bounds__(256) void nearest_kernel(const double *__restrict__ pts, const int64_t *__restrict__ offs,
+// General search of one pixel: rings of cells around its own cell, read from global memory, with the exact stop test
+// (see the header).  Used when a wave's window does not fit its LDS budget or cannot decide a pixel.
+__device__ void ring_search(double qy, double qz, const CaseGrid &G, const int *__restrict__ st,
+                            const double2 *__restrict__ sp, const int *__restrict__ si, double &best, int &bestk) {
+  best = dinf();
+  bestk = -1;            // position in the sorted order; the original index is looked up only on ties and at the end
+  const int cqy = bin1(qy, G.y0, G.invy, G.hy, G.ny), cqz = bin1(qz, G.z0, G.invz, G.hz, G.nz);
+  for (int r = 1;; ++r) {
+    const int y0 = cqy - r > 0 ? cqy - r : 0, y1 = cqy + r < G.ny - 1 ? cqy + r : G.ny - 1;
+    const int z0 = cqz - r > 0 ? cqz - r : 0, z1 = cqz + r < G.nz - 1 ? cqz + r : G.nz - 1;
+    for (int cy = y0; cy <= y1; ++cy) {
+      const bool full = r == 1 || cy == cqy - r || cy == cqy + r;
+      // full row of the box: cells (cy, z0..z1) are consecutive in the sorted order.  Middle rows of ring r >= 2:
+      // only the two end cells (cy, cqz - r) and (cy, cqz + r) are new.
+      for (int part = 0; part < 2; ++part) {
+        int ca, cb;
+        if (full) {
+          if (part) break;
+          ca = cy * G.nz + z0; cb = cy * G.nz + z1 + 1;
+        } else {
+          const int cz = part ? cqz + r : cqz - r;
+          if (cz < 0 || cz > G.nz - 1) continue;
+          ca = cy * G.nz + cz; cb = ca + 1;
+        }
+        const int pa = st[ca], pb = st[cb];
+        for (int k = pa; k < pb; ++k) {
+          const double2 s = sp[k];
+          const double dy = s.x - qy, dz = s.y - qz;
+          const double d = dy * dy + dz * dz;   // two products, one sum, each rounded (contraction is off)
+          if (d < best) { best = d; bestk = k; }
+          else if (d == best && bestk >= 0 && si[k] < si[bestk]) bestk = k;   // ties: the lowest original index
+        }
+      }
+    }
+    if (y0 == 0 && y1 == G.ny - 1 && z0 == 0 && z1 == G.nz - 1) break;    // every cell visited
+    // smallest rounded distance any point outside the box can have (see the header): stop only STRICTLY below it
+    double B = dinf();
+    if (y1 < G.ny - 1) { const double t = G.by(y1 + 1) - qy; B = fmin(B, t * t); }
+    if (y0 > 0)        { const double t = G.by(y0) - qy;     B = fmin(B, t * t); }
+    if (z1 < G.nz - 1) { const double t = G.bz(z1 + 1) - qz; B = fmin(B, t * t); }
+    if (z0 > 0)        { const double t = G.bz(z0) - qz;     B = fmin(B, t * t); }
+    if (best < B) break;
+  }
+}
+
+// The 64 pixels of a wave (8 x 8, ~0.5 x 0.8 mm at the reference grid) fall into a handful of cells, so the wave stages
+// ONE window of cells -- the cells its pixels fall in plus one ring -- into LDS (whole rows of the window are consecutive
+// in the sorted order: one range per cell row) and every lane scans the same ~30-50 points with broadcast LDS reads, no
+// divergence and no dependent global loads.  The scan is exact for a pixel iff its best distance is STRICTLY below the
+// smallest rounded distance a point outside the window can have (the same bound as the ring search, for the window's
+// box); any other pixel -- empty neighbourhoods, oversized windows -- takes the general search.  Pixels outside the
+// walls are written as zeros whatever their nearest point is (:220-221), so they search nothing.
+// Measured (r02, 256 cases): the kernel is a chain of dependent round trips (case record -> cell starts -> points ->
+// values) plus ~35 FP64 distance evaluations per pixel; (p, U) ride with the window so the last round trip is LDS.
+__global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict__ offs,
                                                      int ncase, const double *__restrict__ yf, int H,
                                                      const double *__restrict__ zf, int W, int S,
                                                      const double *__restrict__ wall, int64_t wall_stride,
-                                                     const double *__restrict__ grid, const double *__restrict__ bnd,
+                                                     const double *__restrict__ grid,
                                                      const int *__restrict__ start, const double2 *__restrict__ syz,
+                                                     const double2 *__restrict__ spu,
                                                      const int *__restrict__ sidx, double p_convert,
                                                      double *__restrict__ out) {
-  __shared__ double stage[TILE_H * TILE_W * 5];
+  // [4 waves][WIN_CAP] (y,z), then [4][WIN_CAP] (p,U); the output tile (TILE_H*TILE_W*5 doubles) reuses the same bytes
+  // once every wave has finished with its window
+  __shared__ __align__(16) double lds[4 * WIN_CAP * 4];
+  __shared__ int wids[4][WIN_CAP];
+  static_assert(TILE_H * TILE_W * 5 <= 4 * WIN_CAP * 4, "the output tile must fit the window storage");
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   const int tiles = tiles_x * tiles_y;
   // XCD-aware order: blocks L, L+8, L+16, ... share an XCD (round-robin dispatch), so give each XCD whole cases --
@@ -406,69 +465,133 @@ __global__ __launch_bounds__(256) void nearest_kernel(const double *__restrict__
     tile = (int)(L % tiles);
   }
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const int tid = threadIdx.x;
-  const int i = ty * TILE_H + (tid >> 5), j = tx * TILE_W + (tid & 31);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane >> 3, lc = wave * 8 + (lane & 7);          // row / column inside the block's tile
+  const int i = ty * TILE_H + lr, j = tx * TILE_W + lc;
   const bool live = i < H && j < W;
+  // everything that depends on nothing but the block's coordinates is requested first, in one round trip
   const int64_t beg = offs[cs];
-  const CaseGrid G = load_grid(grid, bnd, cs, beg);
+  const CaseGrid G = load_grid(grid, cs);
+  const double qy = yf[live ? i : 0], qz = zf[live ? j : 0];
+  const double *w = wall + (int64_t)cs * wall_stride;
+  const double ylo = w[2 * S + (live ? j : 0)], yhi = w[2 * S + W + (live ? j : 0)];
   const int *st = start + cell_base(cs, beg) + cs;
   const double2 *sp = syz + beg;
+  const double2 *su = spu + beg;
   const int *si = sidx + beg;
-  const double qy = yf[live ? i : 0], qz = zf[live ? j : 0];
-  double best = dinf();
-  int bestk = -1;            // position in the sorted order; the original index is looked up only on ties and at the end
-  if (live) {
-    const int cqy = bin1(qy, G.y0, G.invy, G.by, G.ny), cqz = bin1(qz, G.z0, G.invz, G.bz, G.nz);
-    for (int r = 1;; ++r) {
-      const int y0 = cqy - r > 0 ? cqy - r : 0, y1 = cqy + r < G.ny - 1 ? cqy + r : G.ny - 1;
-      const int z0 = cqz - r > 0 ? cqz - r : 0, z1 = cqz + r < G.nz - 1 ? cqz + r : G.nz - 1;
-      for (int cy = y0; cy <= y1; ++cy) {
-        const bool full = r == 1 || cy == cqy - r || cy == cqy + r;
-        // full row of the box: cells (cy, z0..z1) are consecutive in the sorted order.  Middle rows of ring r >= 2:
-        // only the two end cells (cy, cqz - r) and (cy, cqz + r) are new.
-        for (int part = 0; part < 2; ++part) {
-          int ca, cb;
-          if (full) {
-            if (part) break;
-            ca = cy * G.nz + z0; cb = cy * G.nz + z1 + 1;
-          } else {
-            const int cz = part ? cqz + r : cqz - r;
-            if (cz < 0 || cz > G.nz - 1) continue;
-            ca = cy * G.nz + cz; cb = ca + 1;
-          }
-          const int pa = st[ca], pb = st[cb];
-          for (int k = pa; k < pb; ++k) {
-            const double2 s = sp[k];
-            const double dy = s.x - qy, dz = s.y - qz;
-            const double d = dy * dy + dz * dz;   // two products, one sum, each rounded (contraction is off)
-            if (d < best) { best = d; bestk = k; }
-            else if (d == best && bestk >= 0 && si[k] < si[bestk]) bestk = k;   // ties: the lowest original index
+  double2 *wpts = (double2 *)lds + wave * WIN_CAP;
+  double2 *wpu = (double2 *)lds + (4 + wave) * WIN_CAP;
+  int *wid = wids[wave];
+  const bool wanted = live && !(qy < ylo || qy > yhi);   // (comparisons with NaN are false, as in numpy: then search)
+
+  // ---- the wave's window of cells (over the pixels that need a nearest point)
+  int cqy = 0, cqz = 0;
+  if (wanted) { cqy = bin1(qy, G.y0, G.invy, G.hy, G.ny); cqz = bin1(qz, G.z0, G.invz, G.hz, G.nz); }
+  int ymin = wanted ? cqy : 0x7fffffff, ymax = wanted ? cqy : -1, zmin = wanted ? cqz : 0x7fffffff, zmax = wanted ? cqz : -1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int a = __shfl_xor(ymin, o), b = __shfl_xor(ymax, o), c = __shfl_xor(zmin, o), d = __shfl_xor(zmax, o);
+    ymin = a < ymin ? a : ymin; ymax = b > ymax ? b : ymax; zmin = c < zmin ? c : zmin; zmax = d > zmax ? d : zmax;
+  }
+  bool fast = false;
+  int T = 0, wy0 = 0, wy1 = -1, wz0 = 0, wz1 = -1;
+  if (ymax >= 0) {                                   // (uniform) some pixel of the wave needs a search
+    wy0 = ymin > 0 ? ymin - 1 : 0; wy1 = ymax < G.ny - 1 ? ymax + 1 : G.ny - 1;
+    wz0 = zmin > 0 ? zmin - 1 : 0; wz1 = zmax < G.nz - 1 ? zmax + 1 : G.nz - 1;
+    const int nrows = wy1 - wy0 + 1;
+    if (nrows <= WIN_ROWS) {
+      int pa = 0, pb = 0;
+      if (lane < nrows) { pa = st[(wy0 + lane) * G.nz + wz0]; pb = st[(wy0 + lane) * G.nz + wz1 + 1]; }
+      const int cnt = pb - pa;
+      int pre = cnt;                                 // inclusive prefix over the rows (lanes 0..7; cnt = 0 beyond nrows)
+#pragma unroll
+      for (int o = 1; o < WIN_ROWS; o <<= 1) {
+        const int t = __shfl_up(pre, o);
+        if (lane >= o) pre += t;
+      }
+      T = __shfl(pre, WIN_ROWS - 1);
+      if (T <= WIN_CAP) {
+        fast = true;
+        // window slot e (two per lane) <- its row's range of the sorted order; all loads leave before any lands
+        int src[2] = {-1, -1};
+#pragma unroll
+        for (int r = 0; r < WIN_ROWS; ++r) {
+          const int pr = __shfl(pre, r), rc = __shfl(cnt, r), ra = __shfl(pa, r);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int e = lane + 64 * h;
+            if (e >= pr - rc && e < pr) src[h] = ra + (e - (pr - rc));
           }
         }
+        double2 a0, a1, u0, u1;
+        int i0 = 0, i1 = 0;
+        if (src[0] >= 0) { a0 = sp[src[0]]; u0 = su[src[0]]; i0 = si[src[0]]; }
+        if (src[1] >= 0) { a1 = sp[src[1]]; u1 = su[src[1]]; i1 = si[src[1]]; }
+        if (src[0] >= 0) { wpts[lane] = a0; wpu[lane] = u0; wid[lane] = i0; }
+        if (src[1] >= 0) { wpts[lane + 64] = a1; wpu[lane + 64] = u1; wid[lane + 64] = i1; }
       }
-      if (y0 == 0 && y1 == G.ny - 1 && z0 == 0 && z1 == G.nz - 1) break;    // every cell visited
-      // smallest rounded distance any point outside the box can have (see the header): stop only STRICTLY below it
-      double B = dinf();
-      if (y1 < G.ny - 1) { const double t = G.by[y1 + 1] - qy; B = fmin(B, t * t); }
-      if (y0 > 0)        { const double t = G.by[y0] - qy;     B = fmin(B, t * t); }
-      if (z1 < G.nz - 1) { const double t = G.bz[z1 + 1] - qz; B = fmin(B, t * t); }
-      if (z0 > 0)        { const double t = G.bz[z0] - qz;     B = fmin(B, t * t); }
-      if (best < B) break;
     }
   }
+  __syncthreads();                                   // (also orders each wave's LDS writes before its reads)
+
   double P = 0.0, U = 0.0;
-  if (live) {
-    const double *w = wall + (int64_t)cs * wall_stride;
-    const double ylo = w[2 * S + j], yhi = w[2 * S + W + j];
-    if (bestk >= 0) {
-      const int besti = si[bestk];
-      P = pts[(beg + besti) * 5 + 3];
-      U = pts[(beg + besti) * 5 + 4];
-      if (P < 0.0) P = 0.0;                      // :182
+  if (wanted) {
+    double best = dinf();
+    bool decided = false;
+    if (fast) {
+      // first pass: strict minimum in scan order, and whether any candidate EQUALLED the running minimum -- only
+      // then (rare) the pass is repeated with the lowest-original-index tie rule
+      int bk = -1;
+      bool tie = false;
+      int k = 0;
+      for (; k + 4 <= T; k += 4) {
+        const double2 s0 = wpts[k], s1 = wpts[k + 1], s2 = wpts[k + 2], s3 = wpts[k + 3];
+        const double y0 = s0.x - qy, z0 = s0.y - qz, y1 = s1.x - qy, z1 = s1.y - qz;
+        const double y2 = s2.x - qy, z2 = s2.y - qz, y3 = s3.x - qy, z3 = s3.y - qz;
+        const double d0 = y0 * y0 + z0 * z0, d1 = y1 * y1 + z1 * z1;   // two products, one sum, each rounded
+        const double d2 = y2 * y2 + z2 * z2, d3 = y3 * y3 + z3 * z3;   // (contraction is off)
+        tie |= d0 == best; if (d0 < best) { best = d0; bk = k; }
+        tie |= d1 == best; if (d1 < best) { best = d1; bk = k + 1; }
+        tie |= d2 == best; if (d2 < best) { best = d2; bk = k + 2; }
+        tie |= d3 == best; if (d3 < best) { best = d3; bk = k + 3; }
+      }
+      for (; k < T; ++k) {
+        const double2 s = wpts[k];
+        const double dy = s.x - qy, dz = s.y - qz;
+        const double d = dy * dy + dz * dz;
+        tie |= d == best; if (d < best) { best = d; bk = k; }
+      }
+      if (tie) {
+        best = dinf(); bk = -1;
+        for (k = 0; k < T; ++k) {
+          const double2 s = wpts[k];
+          const double dy = s.x - qy, dz = s.y - qz;
+          const double d = dy * dy + dz * dz;
+          if (d < best) { best = d; bk = k; }
+          else if (d == best && bk >= 0 && wid[k] < wid[bk]) bk = k;   // ties: the lowest original index
+        }
+      }
+      if (wy0 == 0 && wy1 == G.ny - 1 && wz0 == 0 && wz1 == G.nz - 1) decided = true;   // the window is the whole grid
+      else {
+        double B = dinf();
+        if (wy1 < G.ny - 1) { const double t = G.by(wy1 + 1) - qy; B = fmin(B, t * t); }
+        if (wy0 > 0)        { const double t = G.by(wy0) - qy;     B = fmin(B, t * t); }
+        if (wz1 < G.nz - 1) { const double t = G.bz(wz1 + 1) - qz; B = fmin(B, t * t); }
+        if (wz0 > 0)        { const double t = G.bz(wz0) - qz;     B = fmin(B, t * t); }
+        decided = best < B;
+      }
+      if (decided && bk >= 0) { const double2 pu = wpu[bk]; P = pu.x; U = pu.y; }
     }
-    if (qy < ylo || qy > yhi) { P = 0.0; U = 0.0; }  // :220-221 (comparisons with NaN are false, as in numpy)
+    if (!decided) {
+      int bestk;
+      ring_search(qy, qz, G, st, sp, si, best, bestk);
+      if (bestk >= 0) { const double2 pu = su[bestk]; P = pu.x; U = pu.y; }
+    }
+    if (P < 0.0) P = 0.0;                            // :182
   }
-  double *s5 = stage + tid * 5;
+  __syncthreads();                                   // every wave is done with its window: the tile takes its place
+  double *stage = lds;
+  double *s5 = stage + (lr * TILE_W + lc) * 5;
   s5[0] = qy; s5[1] = qz; s5[2] = P; s5[3] = U; s5[4] = P * p_convert;
   __syncthreads();
   // a tile row = up to 32 pixels x 5 columns = 160 consecutive doubles of the output table
@@ -508,11 +631,11 @@ int resample_launch(const double *pts, const int64_t *case_offsets, int ncase, i
   int *scnt = (int *)(base + L.o_scnt);
   unsigned long long *bbox = (unsigned long long *)(base + L.o_bbox);
   double *grid = (double *)(base + L.o_grid);
-  double *bnd = (double *)(base + L.o_bnd);
   int *start = (int *)(base + L.o_start);
   int *cnt = (int *)(base + L.o_cnt);
   int *cell = (int *)(base + L.o_cell);
   double2 *syz = (double2 *)(base + L.o_syz);
+  double2 *spu = (double2 *)(base + L.o_spu);
   int *sidx = (int *)(base + L.o_sidx);
   const int64_t ninit = (int64_t)ncase * 4 * S;
   hipLaunchKernelGGL(resample_init_kernel, dim3(cdiv(ninit, 256)), dim3(256), 0, st, sacc, scnt, bbox, ncase, S);
@@ -530,25 +653,25 @@ int resample_launch(const double *pts, const int64_t *case_offsets, int ncase, i
   }
   hipLaunchKernelGGL(case_setup_kernel, dim3(ncase), dim3(256), 3 * S * sizeof(double), st, case_offsets, z_samples, S,
                      z_final, W, (const unsigned long long *)sacc, (const int *)scnt, (const unsigned long long *)bbox,
-                     wall, L.wall_stride, grid, bnd, tuning(CFD_TUNE_RESAMPLE_DENSITY) > 0 ? tuning(CFD_TUNE_RESAMPLE_DENSITY) / 4.0 : 1.5);
+                     wall, L.wall_stride, grid, tuning(CFD_TUNE_RESAMPLE_DENSITY) > 0 ? tuning(CFD_TUNE_RESAMPLE_DENSITY) / 4.0 : 1.5);
   CFD_LAUNCH_CHECK();
   if (pblocks > 0) {
     hipLaunchKernelGGL(bin_count_kernel, dim3(pblocks), dim3(256), 0, st, pts, case_offsets, ncase, total,
-                       (const double *)grid, (const double *)bnd, cnt, cell);
+                       (const double *)grid, cnt, cell);
     CFD_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(bin_scan_kernel, dim3(ncase), dim3(256), 0, st, case_offsets, (const double *)grid, cnt, start);
   CFD_LAUNCH_CHECK();
   if (pblocks > 0) {
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(pblocks), dim3(256), 0, st, pts, case_offsets, ncase, total,
-                       (const int *)cell, (const int *)start, cnt, syz, sidx);
+                       (const int *)cell, (const int *)start, cnt, syz, spu, sidx);
     CFD_LAUNCH_CHECK();
   }
   const int64_t tiles = (int64_t)cdiv(W, TILE_W) * cdiv(H, TILE_H);
   CFD_REQUIRE(tiles * ncase < (1LL << 31), "too many tiles in one call");
-  hipLaunchKernelGGL(nearest_kernel, dim3((unsigned)(tiles * ncase)), dim3(256), 0, st, pts, case_offsets, ncase, y_final,
-                     H, z_final, W, S, (const double *)wall, L.wall_stride, (const double *)grid, (const double *)bnd,
-                     (const int *)start, (const double2 *)syz, (const int *)sidx, p_convert, out);
+  hipLaunchKernelGGL(nearest_kernel, dim3((unsigned)(tiles * ncase)), dim3(256), 0, st, case_offsets, ncase, y_final,
+                     H, z_final, W, S, (const double *)wall, L.wall_stride, (const double *)grid,
+                     (const int *)start, (const double2 *)syz, (const double2 *)spu, (const int *)sidx, p_convert, out);
   CFD_LAUNCH_CHECK();
   return CFD_OK;
 }

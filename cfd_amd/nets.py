@@ -338,12 +338,9 @@ class Discriminator(_Net):
                 ops.conv_forward(d_in, P.c(f"c{i}.kernel"), P.m(f"c{i}.bias"), kind, f, out=raw)
                 ops.bn_act(raw, P.m(f"c{i}.bn.gamma"), P.m(f"c{i}.bn.beta"), ACT_LEAKY, out=d, eps=BN_EPS,
                            mean=P.m(f"c{i}.bn.moving_mean"), var=P.m(f"c{i}.bn.moving_var"), use_moving=True)
-        logits = self.buf(pl, "logits", (B, h, w, 1), torch.float32)
-        ops.conv_forward(d, P.c("c6.kernel"), P.m("c6.bias"), CONV_K4S1, 1, act=ACT_NONE, out=logits)
-        if want_logits:
-            return logits
-        out = self.buf(pl, "patch", (B, h, w, 1), torch.float32)
-        ops.conv_forward(d, P.c("c6.kernel"), P.m("c6.bias"), CONV_K4S1, 1, act=ACT_SIGMOID, out=out)
+        out = self.buf(pl, "logits" if want_logits else "patch", (B, h, w, 1), torch.float32)
+        ops.conv_forward(d, P.c("c6.kernel"), P.m("c6.bias"), CONV_K4S1, 1, act=ACT_NONE if want_logits else ACT_SIGMOID,
+                         out=out)
         return out
 
     def update_moving(self, B: int) -> None:
@@ -427,7 +424,7 @@ class CnnRegressor(_Net):
         if training:
             g1 = self.buf(pl, "g1", (B, H, W, 64))
             ops.conv_first(x, None, P.m("g1.kernel"), P.m("g1.bias"), 64, 3, 1, ACT_LEAKY, self.dtype, out=g1)
-            g2 = pl["g2"] = ops.maxpool2(g1)
+            g2 = ops.maxpool2(g1, out=self.buf(pl, "g2", (B, H // 2, W // 2, 64)))
         else:          # inference: conv + LeakyReLU + pool in one pass, the full-resolution activation is never written
             g2 = self.buf(pl, "g2i", (B, H // 2, W // 2, 64))
             ops.conv3_pool2(x, P.m("g1.kernel"), P.m("g1.bias"), 64, ACT_LEAKY, self.dtype, out=g2)
@@ -435,10 +432,10 @@ class CnnRegressor(_Net):
         ops.conv_forward(g2, P.c("g3.kernel"), P.m("g3.bias"), CONV_K3S1, 128, act=ACT_RELU, out=g3)
         g4 = self.buf(pl, "g4", (B, H // 2, W // 2, 256))
         ops.conv_forward(g3, P.c("g4.kernel"), P.m("g4.bias"), CONV_K3S1, 256, act=ACT_RELU, out=g4)
-        g5 = pl["g5"] = ops.maxpool2(g4)
+        g5 = ops.maxpool2(g4, out=self.buf(pl, "g5", (B, H // 4, W // 4, 256)))
         g6 = self.buf(pl, "g6", (B, H // 4, W // 4, 512))
         ops.conv_forward(g5, P.c("g6.kernel"), P.m("g6.bias"), CONV_K3S1, 512, act=ACT_RELU, out=g6)
-        g7 = pl["g7"] = ops.maxpool2(g6)
+        g7 = ops.maxpool2(g6, out=self.buf(pl, "g7", (B, H // 8, W // 8, 512)))
         flat = g7.view(B, -1)  # Flatten in (H,W,C) order == NHWC memory order
         f1 = self.buf(pl, "fc1", (B, 256))
         ops.conv_forward(flat, P.c("fc1.kernel"), P.m("fc1.bias"), DENSE, 256, act=ACT_RELU, out=f1)

@@ -360,12 +360,14 @@ def dropout_mask(shape, rate: float, seed: int, sample0: int = 0, device="cuda")
     return m
 
 
-def maxpool2(x: torch.Tensor) -> torch.Tensor:
+def maxpool2(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, H, W, Cc = x.shape
     if not x.is_contiguous():
         raise _lib.CfdError("maxpool2 input must be dense NHWC")
     _need(H % 2 == 0 and W % 2 == 0, "maxpool2 needs even H and W")
-    y = torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+    y = out if out is not None else torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+    _need(tuple(y.shape) == (B, H // 2, W // 2, Cc) and y.is_contiguous() and y.dtype == x.dtype,
+          f"maxpool2 out must be dense {(B, H // 2, W // 2, Cc)} of x's dtype")
     check(_lib.load().cfd_maxpool2(_ptr(x), _ptr(y), B, H, W, Cc, _DT[x.dtype], _stream()), "cfd_maxpool2")
     return y
 
