@@ -75,7 +75,11 @@ def _predict_chunk() -> int:
 def _forward_chunked(forward, xd: torch.Tensor, with_sample0: bool, **kw) -> torch.Tensor:
     """`forward` over xd in chunks of PREDICT_CHUNK cases, results gathered in one device tensor.  Keras' predict
     batches the same way (batch_size=32).  Every case is independent of its batch here (per-sample BatchNorm statistics,
-    dropout keyed by the sample index `sample0 + i`), so the chunking changes no result; it bounds the activation
+    dropout keyed by the sample index `sample0 + i`), so a chunked call computes the same function of each case as
+    one pass -- equal WITHIN THE STATED TOLERANCE (1e-4 fp32 / 2e-2 bf16), not bit for bit: which BatchNorm-statistics
+    path a layer takes (sums fused into the conv epilogue through fp32 atomics, variance as E[x^2] - mean^2; or the
+    shifted sums of `bn_act`) and the split-K factor depend on the batch size, so the fp32 summation order differs
+    between a batch-1 predict, a full chunk and a ragged tail.  Chunking bounds the activation
     workspace (U at fp32: ~45 MB a case) and keeps every kernel's element count far below 2^31 however many cases
     (configs[2]: 1250 per GPU) one call hands over."""
     B, C = xd.shape[0], _predict_chunk()

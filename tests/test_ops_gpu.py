@@ -304,6 +304,37 @@ def test_conv_stats_bn_apply(kind, B, H, W, cin, cout, drop, dtype, force256):
     assert relerr(cat[..., cout:].float().cpu(), torch.relu(ref)) <= TOL[dtype]
 
 
+def test_fused_bn_statistics_with_large_mean():
+    """The fused path takes the variance as E[x^2] - mean^2 from UNSHIFTED fp32 sums (conv epilogue + atomics), so its
+    error grows like (mean/std)^2 * 2^-24 where `bn_act`'s pixel-0-shifted sums do not: at |mean|/std ~ 30 (a bias of 50
+    on a conv output of std ~1.6; the nets' own layers sit below 3) the normalised output is still within 1e-3 of the
+    oracle, and `bn_act` on the same tensor stays at the 1e-4 bar.  This is why batch / chunk shapes agree 'within
+    tolerance', not bit for bit (keras_api._forward_chunked)."""
+    from cfd_amd import ops
+    dev, dtype = "cuda", torch.float32
+    B, H, W, cin, cout = 2, 32, 32, 64, 256
+    x = rnd((B, H, W, cin), 1)
+    bias = 50.0 + rnd((cout,), 3, 0.5)
+    p = {"l.bn.gamma": 1 + 0.1 * rnd((cout,), 4), "l.bn.beta": 0.1 * rnd((cout,), 5)}
+    wk = rnd((4, 4, cin, cout), 2, 0.05)
+    pre = O.conv2d_same(x, wk, bias, 2)
+    st = {}
+    ref = O.leaky(O.batchnorm(pre, p, "l", True, True, st))
+    ratio = float((st["l"][0].abs() / st["l"][1].sqrt()).median())
+    assert 20 < ratio < 60, ratio
+    stats = (torch.zeros((B, cout), device=dev), torch.zeros((B, cout), device=dev))
+    raw = torch.empty(tuple(pre.shape), dtype=torch.float32, device=dev)
+    _, fused = ops.conv_forward(x.to(dev), ops.pack_conv_weight(wk.to(dev), dtype), bias.to(dev), ops.CONV_K4S2, cout,
+                                out=raw, stats=stats, split_k=1)
+    assert fused
+    y = ops.bn_apply(raw, stats, p["l.bn.gamma"].to(dev), p["l.bn.beta"].to(dev), ops.ACT_LEAKY)
+    y2 = ops.bn_act(raw, p["l.bn.gamma"].to(dev), p["l.bn.beta"].to(dev), ops.ACT_LEAKY)
+    torch.cuda.synchronize()
+    e_fused, e_shifted = relerr(y.cpu(), ref), relerr(y2.cpu(), ref)
+    print(f"mean/std {ratio:.1f}: fused-statistics path {e_fused:.2e}, shifted-sum path {e_shifted:.2e}")
+    assert e_fused <= 1e-3 and e_shifted <= 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool2(dtype):
     from cfd_amd import ops
