@@ -64,6 +64,32 @@ class _Net:
     def plan(self, B: int) -> dict:
         return self._plans.setdefault(B, {})
 
+    # ---- weight gradients beside the data-gradient chain ------------------------------------------------------------
+    # A layer's weight gradient is needed only by the optimiser at the end of the step, while its data gradient heads the
+    # chain of the next layer's backward.  With `side_wgrad` the weight-gradient GEMMs go to a second stream: they fill
+    # the CUs that the short elementwise / split-K epilogue kernels of the chain leave idle.  Their operands (the layer's
+    # input activation and `draw_*`, one buffer per layer) are not rewritten before the next forward.
+    def wgrad_begin(self, side: bool) -> None:
+        self._wg_side = bool(side)
+        if side and getattr(self, "_wg_stream", None) is None:
+            self._wg_stream = torch.cuda.Stream(device=self.device)
+
+    def wgrad(self, fn) -> None:
+        """run `fn` (weight-gradient launches) behind everything enqueued so far, on the side stream if enabled"""
+        if not self._wg_side:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._wg_stream):
+            self._wg_stream.wait_event(ev)
+            fn()
+
+    def wgrad_join(self) -> None:
+        """the caller's stream waits for every weight gradient launched so far"""
+        if self._wg_side:
+            torch.cuda.current_stream().wait_stream(self._wg_stream)
+
     def bn_stats(self, pl: dict, B: int) -> dict:
         """zeroed (sum, sumsq) fp32 (B, C) pairs, one per BatchNorm layer (slices of one flat buffer, one memset):
         the conv epilogue accumulates the per-sample statistics into them where the shape allows it"""
@@ -213,7 +239,7 @@ class Generator(_Net):
                              relu_on_load=inference)
 
     def backward(self, dz: torch.Tensor, x: torch.Tensor, masks: Optional[List[torch.Tensor]] = None, seed: int = 0,
-                 sample0: int = 0, ready=None) -> None:
+                 sample0: int = 0, ready=None, side_wgrad: bool = False) -> None:
         """Backward of the forward that JUST ran with the same (x, masks, seed, sample0): dz = dL/dlogits fp32
         (B,H,W,1).  Writes every trainable gradient of the generator into params.grad (bias gradients of
         convolutions followed by BatchNorm are identically zero and stay at the zero the step memset wrote).
@@ -223,6 +249,7 @@ class Generator(_Net):
         self.check_image(x, dz)
         P, a, B = self.params, self.a, x.shape[0]
         P.wait_transposed()
+        self.wgrad_begin(side_wgrad)
         pl = self.plan(B)
         sums = self.bn_bwd_sums(pl, B)
         enc, dec = a["enc"], a["dec"]
@@ -259,7 +286,7 @@ class Generator(_Net):
                            drop_mask=mask, drop_rate=rate, drop_seed=seed * 16 + i, sample0=sample0, eps=BN_EPS,
                            sums=sums[f"d{i}"])
             g_in = pl[f"cat{i - 1}"] if i > 1 else pl["b"]
-            ops.conv_wgrad(g_in, draw, CONVT_K4S2, f, P.g(f"d{i}.kernel"))
+            self.wgrad(lambda: ops.conv_wgrad(g_in, draw, CONVT_K4S2, f, P.g(f"d{i}.kernel")))
             ready(f"d{i}")
             dnext = self.buf(pl, f"dcat{i - 1}" if i > 1 else "db", g_in.shape)
             ops.conv_forward(draw, P.t(f"d{i}.kernel"), None, CONV_K4S2, g_in.shape[-1], out=dnext)
@@ -269,8 +296,8 @@ class Generator(_Net):
         dpre = self.buf(pl, "dpre_b", b.shape)
         ops.act_bwd(b, dcat, ACT_RELU, dpre)
         e5 = pl["e5"]
-        ops.conv_wgrad(e5, dpre, CONV_K4S2, a["bott"], P.g("b.kernel"))
-        ops.colsum(dpre, P.g("b.bias"))
+        self.wgrad(lambda: (ops.conv_wgrad(e5, dpre, CONV_K4S2, a["bott"], P.g("b.kernel")),
+                            ops.colsum(dpre, P.g("b.bias"))))
         ready("b")
         de = self.buf(pl, "de5", e5.shape)
         ops.conv_forward(dpre, P.t("b.kernel"), None, CONVT_K4S2, e5.shape[-1], out=de)
@@ -283,7 +310,7 @@ class Generator(_Net):
                            de, ACT_LEAKY, draw, P.g(f"e{i}.bn.gamma"), P.g(f"e{i}.bn.beta"),
                            g2=skip_grads[i], act2=ACT_RELU, eps=BN_EPS, sums=sums[f"e{i}"])
             e_prev = pl[f"e{i - 1}"]
-            ops.conv_wgrad(e_prev, draw, CONV_K4S2, f, P.g(f"e{i}.kernel"))
+            self.wgrad(lambda: ops.conv_wgrad(e_prev, draw, CONV_K4S2, f, P.g(f"e{i}.kernel")))
             ready(f"e{i}")
             de = self.buf(pl, f"de{i - 1}", e_prev.shape)
             ops.conv_forward(draw, P.t(f"e{i}.kernel"), None, CONVT_K4S2, e_prev.shape[-1], out=de)
@@ -291,6 +318,7 @@ class Generator(_Net):
         dpre1 = self.buf(pl, "dpre_e1", e1.shape)
         ops.act_bwd(e1, de, ACT_LEAKY, dpre1, g2=skip_grads[1], act2=ACT_RELU)
         ops.conv_first_wgrad(x, None, dpre1, P.g("e1.kernel"), P.g("e1.bias"), 4, 2)
+        self.wgrad_join()
         ready("e1")
 
 
@@ -350,7 +378,7 @@ class Discriminator(_Net):
                                      pl[f"mean_c{i}"], pl[f"var_c{i}"]) for i in range(2, 6)])
 
     def backward(self, dlogits: torch.Tensor, src: torch.Tensor, tgt: torch.Tensor, train_convs: bool = True,
-                 want_input_grad: bool = False):
+                 want_input_grad: bool = False, side_wgrad: bool = False):
         """Backward of the training-mode forward that JUST ran on (src, tgt).  train_convs=False is the
         composite-GAN case: only BatchNorm gamma/beta receive gradients (U/models/generator.py:79-81) and the
         gradient w.r.t. the target image (the generator's output) is returned as fp32 (B,H,W,1)."""
@@ -359,6 +387,7 @@ class Discriminator(_Net):
         if tuple(dlogits.shape) != (B,) + self.patch_shape:
             raise ValueError(f"dlogits must be {(B,) + self.patch_shape}, got {tuple(dlogits.shape)}")
         P.wait_transposed()
+        self.wgrad_begin(side_wgrad and train_convs)
         pl = self.plan(B)
         sums = self.bn_bwd_sums(pl, B)
         c5 = pl["c5"]
@@ -380,7 +409,7 @@ class Discriminator(_Net):
             prev = pl[f"c{i - 1}"]
             kind = CONV_K4S2 if s == 2 else CONV_K4S1
             if train_convs:
-                ops.conv_wgrad(prev, draw, kind, f, P.g(f"c{i}.kernel"))
+                self.wgrad(lambda: ops.conv_wgrad(prev, draw, kind, f, P.g(f"c{i}.kernel")))
             dc = self.buf(pl, f"dc{i - 1}", prev.shape)
             ops.conv_forward(draw, P.t(f"c{i}.kernel"), None, CONVT_K4S2 if s == 2 else ops.CONV_K4S1_BWD,
                              prev.shape[-1], out=dc)
@@ -389,6 +418,7 @@ class Discriminator(_Net):
         ops.act_bwd(c1, dc, ACT_LEAKY, dpre1)
         if train_convs:
             ops.conv_first_wgrad(src, tgt, dpre1, P.g("c1.kernel"), P.g("c1.bias"), 4, 2)
+        self.wgrad_join()
         if not want_input_grad:
             return None
         # d(target image): a transposed conv of dpre1 to ONE channel with w[tap][co] = W[co][tap][ci=1]

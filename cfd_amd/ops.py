@@ -121,8 +121,9 @@ _timer: Optional[KernelTimer] = None
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only fp32 scratch per device (split-K slabs, tap buffers)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only fp32 scratch per device and stream (split-K slabs, tap buffers)."""
+    # one scratch per (device, stream): launches on different streams may overlap and must not share slabs
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
