@@ -260,6 +260,31 @@ def test_upscaled_4x_preprocess_and_train_step():
     print(f"4x grid U fp32: losses {out} vs {ref}; worst grad rel-L2 {wg:.3e}")
 
 
+def test_side_stream_weight_gradients_equal_single_stream(monkeypatch):
+    """CFD_AMD_WGRAD_STREAM=1 moves the weight-gradient GEMMs of G's and D's backward to a second stream; the gradients
+    of one step from identical weights must equal the single-stream ones up to the atomics' commit order (a missing
+    stream dependency would show as garbage or stale gradients)."""
+    from cfd_amd import nets, trainer
+    B = 2
+    x, u, _ = inputs(B)
+    x, u = torch.from_numpy(x).cuda(), torch.from_numpy(u).cuda()
+    grads = []
+    for flag in ("0", "1", "1"):
+        monkeypatch.setenv("CFD_AMD_WGRAD_STREAM", flag)
+        g = nets.Generator("P", dtype=torch.float32, seed=5)
+        d = nets.Discriminator(dtype=torch.float32, seed=6)
+        dtr, gtr = trainer.DiscriminatorTrainer(d), trainer.GanTrainer(g, d)
+        assert trainer._side_wgrad(gtr.dp) == (flag == "1")
+        la = dtr.train_on_batch(x, u, 1.0)
+        gd = d.params.grad[:d.params.n_trainable].clone()
+        lg = gtr.train_on_batch(x, 1.0, u, seed=3)
+        torch.cuda.synchronize()
+        grads.append((la, lg, gd, g.params.grad[:g.params.n_trainable].clone()))
+    for la, lg, gd, gg in grads[1:]:
+        assert np.allclose(la, grads[0][0], rtol=1e-5) and np.allclose(lg, grads[0][1], rtol=1e-5, atol=1e-6)
+        assert rel_l2(gd, grads[0][2]) <= 2e-3 and rel_l2(gg, grads[0][3]) <= 2e-3     # run-to-run noise ~1e-5; stale = O(1)
+
+
 def test_pipelined_step_equals_reference_order():
     """bench.py's training step enqueues the generator's forwards between a D update's all-reduce launch and its
     Adam step (DiscriminatorTrainer.begin / finish, GanTrainer before_d).  Same arithmetic as the reference's order
