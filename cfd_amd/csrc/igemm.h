@@ -23,6 +23,7 @@ struct IgemmParams {
   int nblocks;
   float *stat_sum, *stat_sq;   // optional fused BatchNorm statistics [B][Cout] (accumulated with atomics), or NULL
   int hw_shift, wq_shift;      // log2(Hq*Wq), log2(Wq) when both are powers of two (every reference grid), else -1
+  int pool;                    // 1: the epilogue max-pools 2x2 and y is the POOLED tensor [B][Ho/2][Wo/2][Cout] (igemm256 only)
 };
 
 // first K tile of split-K slice sk (slice = [k_slice(sk), k_slice(sk + 1))): ktiles * sk < 2^31 (host: ktiles <= 16 taps *
@@ -46,6 +47,14 @@ __device__ __forceinline__ void split_pixel(const IgemmParams &p, int m, int &b,
     qy = rem / p.Wq;
     qx = rem - qy * p.Wq;
   }
+}
+
+// pooled launches (IgemmParams::pool): an m tile is 2 image rows x 128 columns, so that every 2x2 pooling window lies
+// inside one tile.  Row `local` (0..255) of tile `mt` -> linear pixel index.  Host: Wq % 128 == 0, Hq even.
+__device__ __forceinline__ int pool_pixel(const IgemmParams &p, int mt, int local) {
+  const int cb = p.Wq >> 7;                 // 128-column blocks per image row
+  const int rp = mt / cb, c = mt - rp * cb; // row pair (over B * Hq / 2), column block
+  return (2 * rp + (local >> 7)) * p.Wq + c * 128 + (local & 127);
 }
 
 // tap t of a class -> input-pixel offset (dy,dx) relative to the class-grid pixel * stride, and the

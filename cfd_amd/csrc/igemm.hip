@@ -473,3 +473,33 @@ extern "C" int cfd_conv_forward_stats(const cfd_conv_desc *d, const void *x, con
                                       void *workspace, float *stat_sum, float *stat_sq, void *stream) {
   return conv_forward_impl(d, x, w, bias, y, workspace, stat_sum, stat_sq, stream);
 }
+
+// conv (stride 1) + bias + monotone activation + MaxPooling2D(2x2): the pooled tensor is the only output
+// (DeltaP/models/generator.py:27-34 at inference).  Runs on the 256-wide kernel with 2-row x 128-column m tiles.
+static bool pool2_fusable(const cfd_conv_desc *d, IgemmParams &p) {
+  if (fill_params(d, p) != CFD_OK) return false;
+  const int es_out = d->out_dtype == CFD_BF16 ? 2 : 4;
+  return (d->kind == CFD_CONV_K3S1 || d->kind == CFD_CONV_K4S1) && d->split_k == 1 && d->Cout % 256 == 0 &&
+         p.Wq % 128 == 0 && p.Hq % 2 == 0 && igemm256_eligible(p, d->dtype) && d->dtype == d->out_dtype &&
+         (d->act == CFD_ACT_NONE || d->act == CFD_ACT_RELU || (d->act == CFD_ACT_LEAKY && d->leaky_slope >= 0.f)) &&
+         d->ldy % (16 / es_out) == 0;
+}
+
+extern "C" int cfd_conv_pool2_fusable(const cfd_conv_desc *d) {
+  IgemmParams p;
+  return d && pool2_fusable(d, p) ? 1 : 0;
+}
+
+extern "C" int cfd_conv_forward_pool2(const cfd_conv_desc *d, const void *x, const void *w, const float *bias, void *y,
+                                      void *stream) {
+  IgemmParams p;
+  CFD_REQUIRE(d != nullptr, "desc is NULL");
+  CFD_REQUIRE(pool2_fusable(d, p),
+              "conv + 2x2 max-pool cannot be fused for this shape (ask cfd_conv_pool2_fusable): needs a stride-1 conv, "
+              "split_k = 1, Cout %% 256 == 0, width %% 128 == 0, even height, equal in/out dtype, a monotone activation");
+  CFD_REQUIRE(x && w && y, "NULL tensor pointer");
+  CFD_REQUIRE(((uintptr_t)y & 15) == 0, "y must be 16-byte aligned");
+  p.x = (const char *)x; p.w = (const char *)w; p.bias = bias; p.y = (char *)y; p.ws = nullptr;
+  p.pool = 1;
+  return igemm256_launch(p, d->dtype, (hipStream_t)stream);
+}

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   unsigned rowoff[4], vmask[4], cur[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int m = m0 + (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow;
+    const int local = (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow;
+    const int m = p.pool ? pool_pixel(p, mt, local) : m0 + local;
     const bool mv = m < p.M;
     const int mm = mv ? m : 0;
     int b, qy, qx;
@@ -433,7 +434,71 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
     }
   }
 
-  if (P.stage_out) {
+  if (p.pool) {
+    // ---- pooled epilogue (conv + bias + monotone activation + 2x2 max-pool, DeltaP/models/generator.py:27-34 at
+    // inference): fragments -> LDS [tile row = 2 image rows x 128 columns][channels], then each pooled pixel takes the
+    // maximum of its four rows and leaves as whole 512-B runs.  The unpooled activation never reaches HBM.  f32 goes in
+    // two passes of 128 channels (a 256-channel f32 tile would need 256 KiB).
+    __syncthreads();   // every wave's tail LDS-DMA has landed (each waited for its own): the stages are dead
+    char *stg = lds + OUT_OFF;
+    const int cb = p.Wq >> 7, rp = mt / cb, cblk = mt - rp * cb;
+    const int half = lane >> 5, ck = lane & 31;   // two pooled pixels per wave instruction, 32 chunks of 16 B each
+    constexpr int NPASS = ES == 2 ? 1 : 2;
+#pragma unroll
+    for (int h = 0; h < NPASS; ++h) {
+      if (h) __syncthreads();                     // the previous half's readers are done
+#pragma unroll
+      for (int ii = 0; ii < 8 / NPASS; ++ii) {
+        const int i = h * (8 / NPASS) + ii;
+        const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int local = (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fr;
+          f32x4 v = acc[i][j] + bv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);   // ns = 1: identity
+          if constexpr (ES == 2) {
+            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *(bf16x4 *)(stg + local * OUT_ROW + nl * 2) = o;
+          } else {
+            *(f32x4 *)(stg + local * OUT_ROW + (nl - h * 128) * 4) = v;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int q = wave * 8 + it * 2 + half;   // pooled column inside the tile (0..63)
+        const char *s0 = stg + (2 * q) * OUT_ROW + ck * 16;
+        const uint4 a = *(const uint4 *)s0, b = *(const uint4 *)(s0 + OUT_ROW);
+        const uint4 c = *(const uint4 *)(s0 + 128 * OUT_ROW), d = *(const uint4 *)(s0 + 129 * OUT_ROW);
+        uint4 o;
+        if constexpr (ES == 2) {
+          auto mx = [](unsigned u0, unsigned u1, unsigned u2, unsigned u3) {
+            // two bf16 per word: compare as floats (a bf16 is the high half of its f32), repack the winners' bits
+            const float l = fmaxf(fmaxf(__uint_as_float(u0 << 16), __uint_as_float(u1 << 16)),
+                                  fmaxf(__uint_as_float(u2 << 16), __uint_as_float(u3 << 16)));
+            const float g = fmaxf(fmaxf(__uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 & 0xffff0000u)),
+                                  fmaxf(__uint_as_float(u2 & 0xffff0000u), __uint_as_float(u3 & 0xffff0000u)));
+            return (__float_as_uint(g) & 0xffff0000u) | (__float_as_uint(l) >> 16);
+          };
+          o.x = mx(a.x, b.x, c.x, d.x); o.y = mx(a.y, b.y, c.y, d.y);
+          o.z = mx(a.z, b.z, c.z, d.z); o.w = mx(a.w, b.w, c.w, d.w);
+        } else {
+          auto mx = [](unsigned u0, unsigned u1, unsigned u2, unsigned u3) {
+            return __float_as_uint(fmaxf(fmaxf(__uint_as_float(u0), __uint_as_float(u1)),
+                                         fmaxf(__uint_as_float(u2), __uint_as_float(u3))));
+          };
+          o.x = mx(a.x, b.x, c.x, d.x); o.y = mx(a.y, b.y, c.y, d.y);
+          o.z = mx(a.z, b.z, c.z, d.z); o.w = mx(a.w, b.w, c.w, d.w);
+        }
+        const int64_t opix = (int64_t)rp * (p.Wq >> 1) + cblk * 64 + q;
+        *(uint4 *)(p.y + (opix * p.ldy + n0 + h * 128) * ES + ck * 16) = o;
+      }
+    }
+  } else if (P.stage_out) {
     // ---- staged epilogue: fragments (bias + activation applied, bf16) -> LDS [pixel][channel] -> whole pixel rows
     __syncthreads();   // every wave's tail LDS-DMA has landed (each waited for its own): the stages are dead
     char *stg = lds + OUT_OFF;
@@ -1116,13 +1181,18 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   // staged bf16 output: whole-tile kernel only (n tile 256), no split-K, 16-B aligned rows
   P.stage_out = ntile == 256 && p.out_bf16 && p.split_k == 1 && p.ldy % 8 == 0 && ((uintptr_t)p.y & 15) == 0 &&
                 p.act != CFD_ACT_SIGMOID && tuning(CFD_TUNE_STAGED_OUT) != 0;
-  const size_t shmem = P.stage_out ? (size_t)OUT_LDS : (size_t)2 * ST_BYTES;
+  if (p.pool) {
+    // (cfd_conv_forward_pool2 checked the shape: stride-1 conv, no split-K, Wq % 128 == 0, Hq even, monotone activation)
+    CFD_REQUIRE(ntile == 256 && p.nclass == 1 && p.split_k == 1 && !p.stat_sum && p.M % 256 == 0, "pooled epilogue: bad launch");
+    P.stage_out = 0;
+  }
+  const size_t shmem = (P.stage_out || p.pool) ? (size_t)OUT_LDS : (size_t)2 * ST_BYTES;
   const int pdt = tuning(CFD_TUNE_IGEMM256_PD);
   // persistent form (igemm256p_kernel): bf16, 256-wide n tiles, more tiles than CUs, every K range even
   // (CFD_TUNE_IGEMM256_PD: 36 forces it where legal, 26 forbids it)
   const int ktiles_all = p.ntaps * p.cpt;
   // (37 = forced on 8 workgroups only: the tests' way to walk several tiles per workgroup with small shapes)
-  const bool p_legal = dtype == CFD_BF16 && ntile == 256 && ktiles_all % (2 * p.split_k) == 0 && p.nblocks >= 8;
+  const bool p_legal = !p.pool && dtype == CFD_BF16 && ntile == 256 && ktiles_all % (2 * p.split_k) == 0 && p.nblocks >= 8;
   const int p_grid = pdt == 37 ? 8 : (p.nblocks >= 256 ? 256 : (p.nblocks / 8) * 8);
   constexpr bool P_DEFAULT = false;   // until measured: the persistent kernel runs only when asked for
   if (p_legal && (pdt == 36 || pdt == 37 || (P_DEFAULT && pdt < 0 && p.nblocks > 256))) {

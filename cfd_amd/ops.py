@@ -185,6 +185,43 @@ def conv_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     return (out, fused) if stats is not None else out
 
 
+def conv_pool2_fusable(x: torch.Tensor, kind: int, cout: int, act: int = ACT_LEAKY, slope: float = LEAKY_SLOPE) -> bool:
+    B, Hi, Wi, cin = x.shape
+    d = ConvDesc(kind=kind, dtype=_DT[x.dtype], out_dtype=_DT[x.dtype], B=B, Hi=Hi, Wi=Wi, Cin=cin, Cout=cout,
+                 ldx=_nhwc(x)[1], ldy=cout, act=act, leaky_slope=slope, split_k=1)
+    lib = _lib.load()
+    # fusable, and worth it: the pooled epilogue cannot split K, so only where the plain launch would not either
+    return bool(lib.cfd_conv_pool2_fusable(C.byref(d))) and lib.cfd_conv_suggest_split_k(C.byref(d)) == 1
+
+
+def conv_forward_pool2(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kind: int, cout: int,
+                       act: int = ACT_LEAKY, out: Optional[torch.Tensor] = None, slope: float = LEAKY_SLOPE) -> torch.Tensor:
+    """MaxPooling2D(2x2)(act(conv(x, w) + bias)) in ONE launch (inference: the unpooled activation is never written).
+    out: (B, Hi/2, Wi/2, cout), same dtype as x.  Shapes: see conv_pool2_fusable."""
+    lib = _lib.load()
+    B, Hi, Wi, cin = x.shape
+    xp, ldx = _nhwc(x)
+    if out is None:
+        out = torch.empty((B, Hi // 2, Wi // 2, cout), dtype=x.dtype, device=x.device)
+    _need(tuple(out.shape) == (B, Hi // 2, Wi // 2, cout) and out.dtype == x.dtype,
+          f"conv_forward_pool2 out is {tuple(out.shape)} {out.dtype}, wanted {(B, Hi // 2, Wi // 2, cout)} {x.dtype}")
+    yp, ldy = _nhwc(out)
+    _numel(w, cout * _TAPS[kind] * cin, "conv weight")
+    _numel(bias, cout, "conv bias", torch.float32)
+    if w.dtype != x.dtype:
+        raise _lib.CfdError(f"weight dtype {w.dtype} != activation dtype {x.dtype}")
+    d = ConvDesc(kind=kind, dtype=_DT[x.dtype], out_dtype=_DT[out.dtype], B=B, Hi=Hi, Wi=Wi, Cin=cin, Cout=cout,
+                 ldx=ldx, ldy=ldy, act=act, leaky_slope=slope, split_k=1)
+    if _timer is not None:
+        e0, e1 = _timer.pair()
+        e0.record()
+    check(lib.cfd_conv_forward_pool2(C.byref(d), xp, _ptr(w), _ptr(bias), yp, _stream()), "cfd_conv_forward_pool2")
+    if _timer is not None:
+        e1.record()
+        _timer.records.append((kind, 2.0 * B * Hi * Wi * cout * _TAPS[kind] * cin, e0, e1))
+    return out
+
+
 def pack_conv_weight(keras_hwio: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     kh, kw, cin, cout = keras_hwio.shape
     src = _dev(keras_hwio).contiguous().float()

@@ -95,6 +95,15 @@ int cfd_conv_stats_fusable(const cfd_conv_desc *desc);
 int cfd_conv_forward_stats(const cfd_conv_desc *desc, const void *x, const void *w, const float *bias, void *y,
                            void *workspace, float *stat_sum, float *stat_sq, void *stream);
 
+/* conv (stride 1: CFD_CONV_K3S1 / CFD_CONV_K4S1) + bias + activation + MaxPooling2D((2,2)) in one launch: y is the
+ * POOLED tensor [B][Hi/2][Wi/2][Cout] with channel stride desc->ldy; the unpooled activation is never written.
+ * Replaces the Conv2D -> LeakyReLU -> MaxPooling2D triples of define_cnn_model at inference
+ * (DeltaP/models/generator.py:27-34).  Only shapes with cfd_conv_pool2_fusable() != 0 (split_k = 1, Cout % 256 == 0,
+ * Wi % 128 == 0, Hi even, out_dtype == dtype, activation NONE / RELU / LEAKY with slope >= 0, which commute with max). */
+int cfd_conv_pool2_fusable(const cfd_conv_desc *desc);
+int cfd_conv_forward_pool2(const cfd_conv_desc *desc, const void *x, const void *w, const float *bias, void *y,
+                           void *stream);
+
 /* weight re-layout: Keras Conv2D (kh,kw,Cin,Cout) fp32 -> packed [Cout][kh][kw][Cin] of `dtype` */
 int cfd_pack_conv_weight(const float *keras_hwio, void *packed, int kh, int kw, int cin, int cout, int dtype,
                          void *stream);

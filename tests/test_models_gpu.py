@@ -178,3 +178,25 @@ def test_inference_paths_equal_training_forward(dtype):
     pi = c.forward(xd, training=False).clone()
     assert torch.equal(pl["g2i"], g2_train)            # the pooled activation, bit for bit
     assert pi.shape == pt.shape and torch.isfinite(pi).all()
+    # at a batch that fills the chip without split-K, g4 / g6 + ReLU + max-pool run as one launch each: the pooled
+    # tensors and the output equal the two-launch path's (training=True only adds tensors; dropout mask all ones * 2
+    # differs, so compare the pooled activations and, through a second inference net forced off the fused path, the output)
+    from cfd_amd import ops
+    B = 32
+    xb = torch.from_numpy(synthetic.model_batch(list(range(B)))[0]).cuda()
+    assert ops.conv_pool2_fusable(torch.empty((B, 32, 256, 128), dtype=dtype, device="cuda"), ops.CONV_K3S1, 256, ops.ACT_RELU)
+    c.forward(xb, training=True, drop_mask=torch.ones((B, 256), dtype=torch.uint8, device="cuda"))
+    plb = c.plan(B)
+    g5_t, g7_t = plb["g5"].clone(), plb["g7"].clone()
+    yi = c.forward(xb, training=False).clone()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    for name, want in (("g5", g5_t), ("g7", g7_t)):
+        got = plb[name]
+        assert float((got.float() - want.float()).abs().max()) <= tol * float(want.float().abs().max()), name
+    saved = ops.conv_pool2_fusable
+    try:
+        ops.conv_pool2_fusable = lambda *a, **k: False
+        yu = c.forward(xb, training=False).clone()
+    finally:
+        ops.conv_pool2_fusable = saved
+    assert float((yi - yu).abs().max()) <= tol * float(yu.abs().max())

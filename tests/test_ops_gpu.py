@@ -96,6 +96,42 @@ def test_conv_forward_igemm256(kind, B, H, W, cin, cout, split_k, dtype, pd):
     _igemm256_case(kind, B, H, W, cin, cout, split_k, dtype, pd)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("kind,B,H,W,cin,cout,act", [
+    ("k3s1", 2, 8, 256, 64, 256, "leaky"),    # two 128-column blocks per image row
+    ("k3s1", 3, 4, 128, 64, 512, "relu"),     # one block per row (tile = two whole rows), two n tiles
+    ("k4s1", 1, 6, 384, 64, 256, "none"),     # three blocks per row, asymmetric 'same' padding, non-power-of-two grid
+])
+def test_conv_forward_pool2(kind, B, H, W, cin, cout, act, dtype):
+    """conv + bias + activation + MaxPooling2D(2x2) in one launch (igemm256's pooled epilogue: 2-row x 128-column m
+    tiles) == oracle conv -> activation -> max_pool2d, written into a channel slice of a wider buffer"""
+    from cfd_amd import ops
+    dev = "cuda"
+    k, code = {"k4s1": (4, ops.CONV_K4S1), "k3s1": (3, ops.CONV_K3S1)}[kind]
+    x = q(rnd((B, H, W, cin), 1), dtype)
+    bias = rnd((cout,), 3, 0.1)
+    wk = q(rnd((k, k, cin, cout), 2, 0.05), dtype)
+    pre = O.conv2d_same(x, wk, bias, 1)
+    a = {"leaky": O.leaky(pre), "relu": torch.relu(pre), "none": pre}[act]
+    ref = torch.nn.functional.max_pool2d(a.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    code_act = {"leaky": ops.ACT_LEAKY, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}[act]
+    buf = torch.full((B, H // 2, W // 2, cout + 64), 7.0, dtype=dtype, device=dev)
+    ops.conv_forward_pool2(x.to(dev).to(dtype), ops.pack_conv_weight(wk.to(dev), dtype), bias.to(dev), code, cout,
+                           act=code_act, out=buf[..., 64:])
+    torch.cuda.synchronize()
+    assert relerr(buf[..., 64:].float().cpu(), ref) <= TOL[dtype]
+    assert bool((buf[..., :64] == 7.0).all())                       # the neighbouring channels are untouched
+    # and the two-launch path gives the same pooled tensor (same GEMM; bf16 rounding commutes with max)
+    y = ops.conv_forward(x.to(dev).to(dtype), ops.pack_conv_weight(wk.to(dev), dtype), bias.to(dev), code, cout,
+                         act=code_act, split_k=1)
+    two = ops.maxpool2(y)
+    # (a bf16 output may round the other way where the two kernels' fp32 sums differ in the last bits)
+    assert relerr(buf[..., 64:].float().cpu(), two.float().cpu()) <= (1e-5 if dtype == torch.float32 else 8e-3)
+    with pytest.raises(Exception):                                   # odd height: refused on the host
+        ops.conv_forward_pool2(x[:, :3].contiguous().to(dev).to(dtype), ops.pack_conv_weight(wk.to(dev), dtype),
+                               bias.to(dev), code, cout, act=code_act)
+
+
 @pytest.mark.parametrize("pd", [36, 37])
 @pytest.mark.parametrize("kind,B,H,W,cin,cout,split_k", [
     ("k4s2", 4, 32, 128, 64, 512, 1),     # 32 tiles of 16 K tiles: 4 per workgroup on 8 workgroups, 1 on 32
