@@ -376,6 +376,14 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const double *__restri
   sidx[beg + pos] = (int)(g - beg);
 }
 
+// ordering point for LDS traffic between the lanes of ONE wave (its LDS operations execute in program order; this keeps
+// the compiler from moving them across and waits for the writes)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 constexpr int TILE_H = 8, TILE_W = 32;   // pixels per block: 8 rows x 32 columns; one wave = 8 rows x 8 columns
 constexpr int WIN_CAP = 128;             // points a wave stages in LDS for its 64 pixels
 constexpr int WIN_ROWS = 8;              // cell rows of a wave's window at most (else the general search)
@@ -443,11 +451,12 @@ __global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict_
                                                      const double2 *__restrict__ spu,
                                                      const int *__restrict__ sidx, double p_convert,
                                                      double *__restrict__ out) {
-  // [4 waves][WIN_CAP] (y,z), then [4][WIN_CAP] (p,U); the output tile (TILE_H*TILE_W*5 doubles) reuses the same bytes
-  // once every wave has finished with its window
+  // per wave: [WIN_CAP] (y,z), then [WIN_CAP] (p,U); the wave's 8 x 8 x 5 output doubles reuse the same bytes once the
+  // wave has finished with its window.  The four waves of a block share NOTHING and never wait for each other (a
+  // block-wide barrier made every wave as slow as the block's slowest lane, e.g. one pixel in the general search).
   __shared__ __align__(16) double lds[4 * WIN_CAP * 4];
   __shared__ int wids[4][WIN_CAP];
-  static_assert(TILE_H * TILE_W * 5 <= 4 * WIN_CAP * 4, "the output tile must fit the window storage");
+  static_assert(64 * 5 <= WIN_CAP * 4, "a wave's output rows must fit its window storage");
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   const int tiles = tiles_x * tiles_y;
   // XCD-aware order: blocks L, L+8, L+16, ... share an XCD (round-robin dispatch), so give each XCD whole cases --
@@ -479,8 +488,8 @@ __global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict_
   const double2 *sp = syz + beg;
   const double2 *su = spu + beg;
   const int *si = sidx + beg;
-  double2 *wpts = (double2 *)lds + wave * WIN_CAP;
-  double2 *wpu = (double2 *)lds + (4 + wave) * WIN_CAP;
+  double2 *wpts = (double2 *)lds + wave * 2 * WIN_CAP;
+  double2 *wpu = wpts + WIN_CAP;
   int *wid = wids[wave];
   const bool wanted = live && !(qy < ylo || qy > yhi);   // (comparisons with NaN are false, as in numpy: then search)
 
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict_
       }
     }
   }
-  __syncthreads();                                   // (also orders each wave's LDS writes before its reads)
+  wave_sync();                                       // the wave's LDS writes before its reads
 
   double P = 0.0, U = 0.0;
   if (wanted) {
@@ -589,18 +598,20 @@ __global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict_
     }
     if (P < 0.0) P = 0.0;                            // :182
   }
-  __syncthreads();                                   // every wave is done with its window: the tile takes its place
-  double *stage = lds;
-  double *s5 = stage + (lr * TILE_W + lc) * 5;
+  wave_sync();                                       // every lane is done with the window: the output rows take its place
+  double *stage = (double *)wpts;
+  double *s5 = stage + lane * 5;                     // lane = row lr (8) x column (8) of the wave's 8 x 8 pixels
   s5[0] = qy; s5[1] = qz; s5[2] = P; s5[3] = U; s5[4] = P * p_convert;
-  __syncthreads();
-  // a tile row = up to 32 pixels x 5 columns = 160 consecutive doubles of the output table
-  const int cols = (W - tx * TILE_W) < TILE_W ? (W - tx * TILE_W) : TILE_W;
-  for (int e = tid; e < TILE_H * TILE_W * 5; e += 256) {
-    const int r = e / (TILE_W * 5), k = e - r * (TILE_W * 5);
+  wave_sync();
+  // a row of the wave's pixels = up to 8 pixels x 5 columns = 40 consecutive doubles of the output table
+  const int col0 = tx * TILE_W + wave * 8;
+  const int cols = (W - col0) < 8 ? (W - col0) : 8;  // (<= 0: the whole wave is outside the image)
+#pragma unroll
+  for (int e = lane; e < 64 * 5; e += 64) {
+    const int r = e / 40, k = e - r * 40;
     const int row = ty * TILE_H + r;
     if (row < H && k < cols * 5)
-      out[(((int64_t)cs * H + row) * W + tx * TILE_W) * 5 + k] = stage[e];
+      out[(((int64_t)cs * H + row) * W + col0) * 5 + k] = stage[e];
   }
 }
 

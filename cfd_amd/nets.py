@@ -83,7 +83,11 @@ class _Net:
         ev.record()
         with torch.cuda.stream(self._wg_stream):
             self._wg_stream.wait_event(ev)
-            fn()
+            ops._ws_lane = 1               # its own split-K / split-M scratch: these launches overlap the main stream's
+            try:
+                fn()
+            finally:
+                ops._ws_lane = 0
 
     def wgrad_join(self) -> None:
         """the caller's stream waits for every weight gradient launched so far"""

@@ -80,6 +80,7 @@ def set_tuning(key: int, value: int) -> None:
 
 
 _ws_cache = {}
+_ws_lane = 0          # which scratch `_workspace` hands out: 0 = the launch stream's, 1 = the weight-gradient side stream's
 
 
 class KernelTimer:
@@ -121,9 +122,10 @@ _timer: Optional[KernelTimer] = None
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only fp32 scratch per device and stream (split-K slabs, tap buffers)."""
-    # one scratch per (device, stream): launches on different streams may overlap and must not share slabs
-    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    """Grow-only fp32 scratch per device and lane (split-K slabs, tap buffers)."""
+    # one scratch per (device, lane): launches that may overlap (nets._Net.wgrad's side stream sets lane 1) must not
+    # share slabs
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _ws_lane)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
