@@ -212,6 +212,23 @@ def pmc_traffic(workload):
     return round(b / n), (round(mb, 4) if mb is not None else None)
 
 
+def pmc_traffic_resample():
+    """HBM bytes of ONE cfd_resample_nearest call (all of its launches together), from the committed PMC passes of
+    `bench.py --workload resample` (profiles/r*_resample_summary.json); None when none is committed."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_resample_summary.json")))
+    if not fs:
+        return None
+    try:
+        ks = json.load(open(fs[-1]))["kernels"]
+        calls = ks["nearest_kernel"]["launches"]
+        tot = sum(k["launches"] * (k.get("hbm_read_bytes_per_launch", 0) + k.get("hbm_write_bytes_per_launch", 0))
+                  for k in ks.values())
+        return round(tot / calls)
+    except Exception:
+        return None
+
+
 def timed_steps(step_fn, steps, warmup, world):
     """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks; -> seconds"""
     for s in range(warmup):
@@ -313,9 +330,10 @@ def run_resample_workload(steps, warmup, rank, world, cpu_base, ncase=256):
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b in ev) / n_roof
         gbs = job.algorithmic_bytes() / (ms * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel="wall_slices+wall_interp+nearest_kernel (one cfd_resample_nearest call)",
+        roof = dict(bound="hbm", kernel="one cfd_resample_nearest call = init + points_pass + case_setup + bin_count/scan/scatter + "
+                                        "nearest_kernel (68 % of the call)",
                     achieved=round(gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 5),
-                    traffic=None, algorithmic_bytes_per_launch=job.algorithmic_bytes(), avg_launch_us=round(ms * 1e3, 2))
+                    traffic=pmc_traffic_resample(), algorithmic_bytes_per_launch=job.algorithmic_bytes(), avg_launch_us=round(ms * 1e3, 2))
     out = {"value": round(world * ncase * H * W * steps / dt, 1), "unit": "queries/s", "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "dtype": "f64",
            "cases_per_s": round(world * ncase * steps / dt, 1),
