@@ -281,14 +281,31 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   }
 }
 
-// sum split-K slabs + bias + activation + convert + strided NHWC store
-__global__ void splitk_epilogue_kernel(const float *ws, const float *bias, char *y, int64_t npix, int Cout, int ldy,
-                                       int split_k, int act, float slope, int out_bf16) {
+// sum split-K slabs + bias + activation + convert + strided NHWC store.  One thread = four consecutive channels of one
+// pixel (16-B slab loads), one pass, no grid cap; the scalar form serves Cout % 4 != 0 (the one-channel layers).
+template <int V>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float *__restrict__ ws, const float *__restrict__ bias,
+                                                             char *__restrict__ y, int64_t npix, int Cout, int ldy,
+                                                             int split_k, int act, float slope, int out_bf16) {
   const int64_t total = npix * Cout;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t pix = idx / Cout;
-    const int n = (int)(idx - pix * Cout);
+  const int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+  if (idx >= total) return;
+  const int64_t pix = idx / Cout;
+  const int n = (int)(idx - pix * Cout);
+  if constexpr (V == 4) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < split_k; ++k) s += *(const f32x4 *)(ws + (int64_t)k * total + idx);
+    if (bias) s += *(const f32x4 *)(bias + n);
+    const float ns = act_neg_scale(act, slope);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = act == CFD_ACT_SIGMOID ? apply_act(s[r], act, slope) : apply_act_linear(s[r], ns);
+    if (out_bf16) {
+      bf16x4 o = {(bf16)s[0], (bf16)s[1], (bf16)s[2], (bf16)s[3]};
+      *(bf16x4 *)(y + (pix * ldy + n) * 2) = o;
+    } else {
+      *(f32x4 *)(y + (pix * ldy + n) * 4) = s;
+    }
+  } else {
     float s = 0.f;
     for (int k = 0; k < split_k; ++k) s += ws[(int64_t)k * total + idx];
     if (bias) s += bias[n];
@@ -456,9 +473,15 @@ static int conv_forward_impl(const cfd_conv_desc *d, const void *x, const void *
   if (p.split_k > 1) {
     const int64_t npix = (int64_t)p.B * p.Ho * p.Wo;
     const int64_t total = npix * p.Cout;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, (const float *)workspace, bias,
-                       (char *)y, npix, p.Cout, p.ldy, p.split_k, p.act, p.slope, p.out_bf16);
+    const bool v4 = p.Cout % 4 == 0 && p.ldy % 4 == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0);
+    const int64_t threads = v4 ? total / 4 : total;
+    CFD_REQUIRE((threads + 255) / 256 < (1LL << 31), "split-K epilogue grid too large");
+    if (v4)
+      hipLaunchKernelGGL(splitk_epilogue_kernel<4>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                         (const float *)workspace, bias, (char *)y, npix, p.Cout, p.ldy, p.split_k, p.act, p.slope, p.out_bf16);
+    else
+      hipLaunchKernelGGL(splitk_epilogue_kernel<1>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                         (const float *)workspace, bias, (char *)y, npix, p.Cout, p.ldy, p.split_k, p.act, p.slope, p.out_bf16);
     CFD_LAUNCH_CHECK();
   }
   return CFD_OK;
