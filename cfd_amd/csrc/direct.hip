@@ -16,6 +16,7 @@ namespace cfd {
 // pixels of one output row per tile: 128 amortises the patch staging and its two barriers over 16 pixels per thread
 // (32 left 4 per thread between barriers)
 constexpr int CONV_FIRST_TX = 128;
+constexpr int WL_LD = 256 + 4;           // conv_first: Cout <= 256 (CG <= 256 / ... checked on the host)
 
 template <int KS, int S, int CIN, int CPT, typename TO>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, const float *__restrict__ x2,
@@ -41,16 +42,25 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
   const bool sig1 = act == CFD_ACT_SIGMOID, sig2 = act2 == CFD_ACT_SIGMOID;
 
   // weights of my channels: wreg[c][tap*CIN + ci] -- loaded ONCE per block; the block then walks many tiles
-  // (a per-tile block re-read 128 KB of weights to write 32 KB of output)
+  // (a per-tile block re-read 128 KB of weights to write 32 KB of output).  They come through LDS: read straight from
+  // global memory every lane's NW * CPT loads hit a different 64-B row (stride NW floats between channel groups), which
+  // at small batch -- one tile per block -- cost more than the tile itself (e1 at B = 16: 75 us for 134 MB of output).
+  __shared__ __align__(16) float wl[NW][WL_LD];      // [tap][channel], rows padded to keep 16-B alignment
+  for (int e = tid; e < Cout * NW; e += 256) wl[e % NW][e / NW] = w[e];
+  __syncthreads();
   float wreg[CPT][NW];
   float breg[CPT];
 #pragma unroll
-  for (int c = 0; c < CPT; ++c) {
-    const float *wp = w + (size_t)(cg * CPT + c) * NW;
+  for (int k = 0; k < NW; ++k) {
 #pragma unroll
-    for (int k = 0; k < NW; ++k) wreg[c][k] = wp[k];
-    breg[c] = bias ? bias[cg * CPT + c] : 0.f;
+    for (int c4 = 0; c4 < CPT; c4 += 4) {
+      const f32x4 t = *(const f32x4 *)&wl[k][cg * CPT + c4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wreg[c4 + c][k] = t[c];
+    }
   }
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) breg[c] = bias ? bias[cg * CPT + c] : 0.f;
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int bid = tile;
