@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcfd_amd.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 CONV_K4S2, CONV_K4S1, CONV_K3S1, CONVT_K4S2, DENSE, CONV_K4S1_BWD = 0, 1, 2, 3, 4, 5
-TUNE_IGEMM256, TUNE_IGEMM256_PD, TUNE_WGRAD256, TUNE_CLASS_ORDER, TUNE_STAGED_OUT, TUNE_RESAMPLE_DENSITY = 0, 1, 2, 3, 4, 5
+TUNE_IGEMM256, TUNE_IGEMM256_PD, TUNE_WGRAD256, TUNE_CLASS_ORDER, TUNE_STAGED_OUT, TUNE_RESAMPLE_DENSITY, TUNE_NTILE = 0, 1, 2, 3, 4, 5, 6
 
 
 class ConvDesc(C.Structure):
@@ -110,6 +110,11 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
+    # A/B switch for whole-program runs (bench.py, the CLIs): CFD_AMD_TUNE="6=256,0=1" -> cfd_set_tuning(6, 256), (0, 1)
+    for kv in filter(None, os.environ.get("CFD_AMD_TUNE", "").split(",")):
+        k, v = kv.split("=")
+        if lib.cfd_set_tuning(int(k), int(v)) != 0:
+            raise CfdError(f"CFD_AMD_TUNE: bad entry {kv!r}")
     _lib = lib
     return lib
 

@@ -1131,7 +1131,20 @@ bool igemm256_eligible(const IgemmParams &p, int dtype) {
 }
 
 // n-tile of the variant that runs this layer: 256 when Cout allows it, else the 128 x 256 variant
-int igemm256_ntile(const IgemmParams &p) { return p.Cout % 256 == 0 ? 256 : 128; }
+// n-tile of the variant that runs this layer: 256 when Cout allows it, else the 128 x 256 variant -- and also the 128 x 256
+// variant for bf16 layers that give the 256 x 256 kernel at most half a chip of tiles (small M: U e4 / d2 and every
+// discriminator layer at B = 16, P e4 .. d2 at B = 128): twice the blocks means half the split-K factor, i.e. half the fp32
+// slab traffic, or none (measured per layer, scripts/layer_bench.py --ntile 128: 8-20 % faster up to 128 tiles, slower from
+// 256 tiles on)
+int igemm256_ntile(const IgemmParams &p) {
+  if (p.Cout % 256 != 0) return 128;
+  if (p.pool) return 256;
+  const int t = tuning(CFD_TUNE_NTILE);
+  if (t == 128 || t == 256) return t;
+  const bool bf = p.cpt * 64 == p.Cin;
+  const int64_t blocks256 = (int64_t)cdiv(p.M, 256) * (p.Cout / 256) * p.nclass;
+  return bf && blocks256 <= 128 ? 128 : 256;
+}
 
 int igemm256_block_count(const IgemmParams &p) {
   return cdiv(p.M, 256) * (p.Cout / igemm256_ntile(p)) * p.nclass * p.split_k;

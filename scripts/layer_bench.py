@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--wgrad256", type=int, default=-1)
     ap.add_argument("--class-order", type=int, default=-1, help="-1 heuristic, 0 class-major, 1 interleaved")
     ap.add_argument("--staged-out", type=int, default=-1, help="-1/1 staged bf16 epilogue where legal, 0 off")
+    ap.add_argument("--ntile", type=int, default=-1, help="-1 heuristic, 128 / 256: n tile of the ping-pong kernels")
     ap.add_argument("--only", default="", help="comma list of layer names, e.g. e2,d4")
     args = ap.parse_args()
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -77,6 +78,7 @@ def main():
     ops.set_tuning(ops.TUNE_WGRAD256, args.wgrad256)
     ops.set_tuning(ops.TUNE_CLASS_ORDER, args.class_order)
     ops.set_tuning(ops.TUNE_STAGED_OUT, args.staged_out)
+    ops.set_tuning(ops.TUNE_NTILE, args.ntile)
     B = args.batch
     nets = ["U", "P", "D", "DeltaP"] if args.net == "all" else [args.net]
     modes = args.modes.split(",")
