@@ -88,8 +88,9 @@ class KernelTimer:
     stream IS the stream the kernels are launched on) and records their algorithmic FLOPs.
     Used by bench.py for the `roofline` object; off by default (zero overhead)."""
 
-    def __init__(self, max_launches: int = 1024):
+    def __init__(self, max_launches: int = 1024, sync: bool = True):
         self.records = []   # (tag, flops, start_event, end_event)
+        self.sync = sync    # False: the caller keeps work queued ahead of the first bracket (bench.py's head start)
         # torch creates the HIP event at its first record(): do that here, outside every bracket, so that a bracket
         # costs two hipEventRecord calls and nothing else
         self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * max_launches)]
@@ -103,7 +104,8 @@ class KernelTimer:
 
     def __enter__(self):
         global _timer
-        torch.cuda.synchronize()
+        if self.sync:
+            torch.cuda.synchronize()
         _timer = self
         return self
 
