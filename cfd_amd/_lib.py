@@ -48,6 +48,8 @@ SIGNATURES = {
     "cfd_conv_first": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "cfd_convT_out": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cfd_convT_out_relu": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cfd_convT_out_bn": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
+                              _i, _vp]),
     "cfd_conv3_pool2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "cfd_bn_act": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, C.c_uint64, _i64, _vp, _i, _vp, _i, _i, _i, _i, _f, _i,
                         _i, _f, _i, _vp]),

@@ -308,6 +308,155 @@ __global__ __launch_bounds__(256) void tapgemm_f32_kernel(const float *__restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// convT_out, step 1 with the last decoder block's BatchNorm + ReLU applied AS THE OPERAND IS LOADED (inference):
+//   x[pixel] = [ ReLU(BN(raw[pixel][0..C1))) | ReLU(skip[pixel][0..C2)) ]      (generator.py:33-40, 70-71)
+// `raw` is the pre-BatchNorm output of the last transposed convolution, whose per-sample sums the conv epilogue (or
+// cfd_bn_stats) accumulated; the normalised activation is never written and never re-read (U at B = 128: 0.5 GB each
+// way).  Same arithmetic, in the same order, as cfd_bn_apply followed by tapgemm: fmaf(x, scale, shift), ReLU, rounding
+// to the compute dtype, one MFMA chain over [raw | skip] -- bit-identical taps.
+// Block = (sample, chunk of pixels): the sample's scale / shift sit in LDS, one wave owns 16 pixels per iteration.
+// ---------------------------------------------------------------------------------------------
+template <int C1>
+__device__ __forceinline__ void bn_coeffs_to_lds(float *s_sc, float *s_sh, const float *__restrict__ ssum,
+                                                 const float *__restrict__ ssq, const float *__restrict__ gamma,
+                                                 const float *__restrict__ beta, float eps, int b, int HW) {
+  const float inv_n = 1.f / (float)HW;
+  for (int c = threadIdx.x; c < C1; c += 256) {
+    // (bn_apply_kernel's expressions, so that both paths normalise with the same numbers)
+    const float mean = ssum[(size_t)b * C1 + c] * inv_n;
+    const float v = fmaf(-mean, mean, ssq[(size_t)b * C1 + c] * inv_n);
+    const float var = v > 0.f ? v : 0.f;
+    const float sc = gamma[c] * rsqrtf(var + eps);
+    s_sc[c] = sc;
+    s_sh[c] = beta[c] - mean * sc;
+  }
+  __syncthreads();
+}
+
+template <typename TR> __device__ __forceinline__ void load8(const TR *p, float (&f)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float *p, float (&f)[8]) {
+  const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+}
+template <> __device__ __forceinline__ void load8<bf16>(const bf16 *p, float (&f)[8]) {
+  const bf16x8 a = *(const bf16x8 *)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (float)a[i];
+}
+
+template <int C1, int C2, typename TR>
+__global__ __launch_bounds__(256) void tapgemm_bn_bf16_kernel(const TR *__restrict__ raw, int ldraw,
+                                                             const float *__restrict__ ssum, const float *__restrict__ ssq,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float eps, const bf16 *__restrict__ skip, int ldskip,
+                                                             const bf16 *__restrict__ w, float *__restrict__ taps, int HW,
+                                                             int chunks, int pix_per_chunk) {
+  constexpr int CIN = C1 + C2, S1 = C1 / 64, S2 = C2 / 64;
+  __shared__ __align__(16) float s_sc[C1], s_sh[C1];
+  const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+  bn_coeffs_to_lds<C1>(s_sc, s_sh, ssum, ssq, gamma, beta, eps, b, HW);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  bf16x8 wf[S1 + S2][2];
+#pragma unroll
+  for (int s = 0; s < S1 + S2; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) wf[s][h] = *(const bf16x8 *)(w + (size_t)fr * CIN + s * 64 + fq * 16 + h * 8);
+  const int p0 = chunk * pix_per_chunk;
+  const int p1 = p0 + pix_per_chunk < HW ? p0 + pix_per_chunk : HW;       // (host: HW % 16 == 0, pix_per_chunk % 16 == 0)
+  for (int pt = p0 + wave * 16; pt < p1; pt += 64) {
+    const size_t pix = (size_t)b * HW + pt + fr;
+    const TR *rp = raw + pix * ldraw + fq * 16;
+    const bf16 *sp = skip + pix * ldskip + fq * 16;
+    bf16x8 xa[S1 + S2][2];
+#pragma unroll
+    for (int s = 0; s < S2; ++s) {
+      xa[S1 + s][0] = relu8(*(const bf16x8 *)(sp + s * 64));
+      xa[S1 + s][1] = relu8(*(const bf16x8 *)(sp + s * 64 + 8));
+    }
+#pragma unroll
+    for (int s = 0; s < S1; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float f[8];
+        load8<TR>(rp + s * 64 + h * 8, f);
+        const int c = s * 64 + fq * 16 + h * 8;
+        const f32x4 a0 = *(const f32x4 *)&s_sc[c], a1 = *(const f32x4 *)&s_sc[c + 4];
+        const f32x4 b0 = *(const f32x4 *)&s_sh[c], b1 = *(const f32x4 *)&s_sh[c + 4];
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[i] = (bf16)apply_act_linear(fmaf(f[i], a0[i], b0[i]), 0.f);
+          o[4 + i] = (bf16)apply_act_linear(fmaf(f[4 + i], a1[i], b1[i]), 0.f);
+        }
+        xa[s][h] = o;
+      }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S1 + S2; ++s) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][0], xa[s][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][1], xa[s][1], acc, 0, 0, 0);
+    }
+    *(f32x4 *)(taps + pix * 16 + fq * 4) = acc;
+  }
+}
+
+template <int C1, int C2>
+__global__ __launch_bounds__(256) void tapgemm_bn_f32_kernel(const float *__restrict__ raw, int ldraw,
+                                                            const float *__restrict__ ssum, const float *__restrict__ ssq,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            float eps, const float *__restrict__ skip, int ldskip,
+                                                            const float *__restrict__ w, float *__restrict__ taps, int HW,
+                                                            int chunks, int pix_per_chunk) {
+  constexpr int CIN = C1 + C2, S1 = C1 / 32, S2 = C2 / 32;
+  __shared__ __align__(16) float s_sc[C1], s_sh[C1];
+  const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+  bn_coeffs_to_lds<C1>(s_sc, s_sh, ssum, ssq, gamma, beta, eps, b, HW);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 wf[S1 + S2][2];
+#pragma unroll
+  for (int s = 0; s < S1 + S2; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) wf[s][h] = *(const f32x4 *)(w + (size_t)fr * CIN + s * 32 + fq * 8 + h * 4);
+  const int p0 = chunk * pix_per_chunk;
+  const int p1 = p0 + pix_per_chunk < HW ? p0 + pix_per_chunk : HW;
+  for (int pt = p0 + wave * 16; pt < p1; pt += 64) {
+    const size_t pix = (size_t)b * HW + pt + fr;
+    const float *rp = raw + pix * ldraw + fq * 8;
+    const float *sp = skip + pix * ldskip + fq * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S1 + S2; ++s) {
+      f32x4 a[2];
+      if (s < S1) {
+        const int c = s * 32 + fq * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 v = *(const f32x4 *)(rp + s * 32 + h * 4);
+          const f32x4 sc = *(const f32x4 *)&s_sc[c + h * 4], sh = *(const f32x4 *)&s_sh[c + h * 4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[h][e] = apply_act_linear(fmaf(v[e], sc[e], sh[e]), 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 v = *(const f32x4 *)(sp + (s - S1) * 32 + h * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[h][e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][0][e], a[0][e], acc, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][1][e], a[1][e], acc, 0, 0, 0);
+    }
+    *(f32x4 *)(taps + pix * 16 + fq * 4) = acc;
+  }
+}
+
 // step 2: out[b][oy][ox] = bias + sum over the (<=4) (input pixel, tap) pairs with oy = 2*iy + kh - 1
 __global__ void convT_out_gather_kernel(const float *__restrict__ taps, const float *__restrict__ bias,
                                         float *__restrict__ y, float *__restrict__ logits, int B, int Hi, int Wi,
@@ -464,6 +613,53 @@ extern "C" int cfd_convT_out_relu(const void *x, int ldx, const void *w, const f
   } else
   TAPGEMM(512) TAPGEMM(256) TAPGEMM(128) TAPGEMM(64) { CFD_FAIL(CFD_EUNSUPPORTED, "convT_out: Cin=%d not built", Cin); }
 #undef TAPGEMM
+  CFD_LAUNCH_CHECK();
+  const int64_t total = (int64_t)B * 4 * Hi * Wi;
+  const int gb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(convT_out_gather_kernel, dim3(gb), dim3(256), 0, st, (const float *)taps, bias, y, logits, B, Hi,
+                     Wi, apply_sigmoid);
+  CFD_LAUNCH_CHECK();
+  return CFD_OK;
+}
+
+extern "C" int cfd_convT_out_bn(const void *raw, int ldraw, int raw_dtype, const float *stat_sum, const float *stat_sq,
+                                const float *gamma, const float *beta, float eps, const void *skip, int ldskip,
+                                const void *w, const float *bias, float *taps, float *y, float *logits, int B, int Hi,
+                                int Wi, int C1, int C2, int dtype, int apply_sigmoid, void *stream) {
+  CFD_REQUIRE(raw && stat_sum && stat_sq && gamma && beta && skip && w && taps && y, "NULL pointer");
+  CFD_REQUIRE(dtype == CFD_BF16 || dtype == CFD_F32, "bad dtype");
+  CFD_REQUIRE(raw_dtype == dtype || (raw_dtype == CFD_F32 && dtype == CFD_BF16), "raw dtype %d with compute dtype %d", raw_dtype, dtype);
+  const int va = dtype == CFD_BF16 ? 8 : 4, vr = raw_dtype == CFD_BF16 ? 8 : 4;
+  CFD_REQUIRE(ldraw >= C1 && ldraw % vr == 0 && ldskip >= C2 && ldskip % va == 0, "bad ldraw=%d / ldskip=%d", ldraw, ldskip);
+  CFD_REQUIRE(((uintptr_t)raw & 15) == 0 && ((uintptr_t)skip & 15) == 0 && ((uintptr_t)w & 15) == 0, "operands must be 16-B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t hw64 = (int64_t)Hi * Wi, npix64 = (int64_t)B * hw64;
+  CFD_REQUIRE(B > 0 && hw64 > 0 && npix64 < (1LL << 31) && hw64 % 16 == 0, "bad grid %d x %d x %d (H*W must be a multiple of 16)", B, Hi, Wi);
+  const int HW = (int)hw64;
+  // block = (sample, chunk of pixels); chunks as large as still give >= 1024 blocks (the weights are re-read per block)
+  int ppc = 1024;
+  while (ppc > 64 && (int64_t)B * cdiv(HW, ppc) < 1024) ppc >>= 1;
+  const int chunks = cdiv(HW, ppc);
+  const int blocks = B * chunks;
+#define TAPGEMM_BN(A, C)                                                                                               \
+  if (C1 == A && C2 == C) {                                                                                            \
+    if (dtype == CFD_F32)                                                                                              \
+      hipLaunchKernelGGL((tapgemm_bn_f32_kernel<A, C>), dim3(blocks), dim3(256), 0, st, (const float *)raw, ldraw,     \
+                         stat_sum, stat_sq, gamma, beta, eps, (const float *)skip, ldskip, (const float *)w, taps, HW, \
+                         chunks, ppc);                                                                                 \
+    else if (raw_dtype == CFD_BF16)                                                                                    \
+      hipLaunchKernelGGL((tapgemm_bn_bf16_kernel<A, C, bf16>), dim3(blocks), dim3(256), 0, st, (const bf16 *)raw,      \
+                         ldraw, stat_sum, stat_sq, gamma, beta, eps, (const bf16 *)skip, ldskip, (const bf16 *)w,      \
+                         taps, HW, chunks, ppc);                                                                       \
+    else                                                                                                               \
+      hipLaunchKernelGGL((tapgemm_bn_bf16_kernel<A, C, float>), dim3(blocks), dim3(256), 0, st, (const float *)raw,    \
+                         ldraw, stat_sum, stat_sq, gamma, beta, eps, (const bf16 *)skip, ldskip, (const bf16 *)w,      \
+                         taps, HW, chunks, ppc);                                                                       \
+  } else
+  TAPGEMM_BN(256, 256) TAPGEMM_BN(128, 128) TAPGEMM_BN(64, 64) {
+    CFD_FAIL(CFD_EUNSUPPORTED, "convT_out_bn: channels %d + %d not built (256+256, 128+128, 64+64)", C1, C2);
+  }
+#undef TAPGEMM_BN
   CFD_LAUNCH_CHECK();
   const int64_t total = (int64_t)B * 4 * Hi * Wi;
   const int gb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

@@ -19,6 +19,8 @@ Activation buffers are cached per batch size; a forward allocates nothing after 
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional
 
 import torch
@@ -39,6 +41,7 @@ DROP_RATE = 0.5
 # elements per sample: those tensors cost little bandwidth and rounding them BEFORE the mean is
 # subtracted is the largest single error term of the bf16 path.  Larger (high-resolution) layers keep bf16.
 RAW_F32_MAX_ELEMS = 524288
+FUSE_OUT_BN = os.environ.get("CFD_AMD_FUSE_OUT_BN", "1") != "0"   # inference: the last decoder block's BatchNorm + ReLU run inside the output layer's load
 BN_SPLIT_MIN_ELEMS = 1 << 18      # per-sample tensor size from which BatchNorm statistics get their own chip-wide pass
 
 
@@ -236,6 +239,17 @@ class Generator(_Net):
                 if masks is not None:
                     mask = masks[mi]
                 mi += 1
+            if FUSE_OUT_BN and inference and i == len(dec) and not drop and f == skips[i - 1] and f in (64, 128, 256) and (h * w) % 16 == 0:
+                # the last block's BatchNorm + ReLU happen inside the output layer as it loads `raw`: the normalised
+                # tensor (the largest activation of the net) is neither written nor read back
+                name = f"d{i}"
+                _y, fused = ops.conv_forward(g, P.c(name + ".kernel"), P.m(name + ".bias"), CONVT_K4S2, f, out=raw,
+                                             stats=st[name])
+                if not fused:
+                    ops.bn_stats(raw, st[name])
+                return ops.convT_out_bn(raw, st[name], P.m(name + ".bn.gamma"), P.m(name + ".bn.beta"),
+                                        cats[i - 1][..., f:], P.c("out.kernel"), P.m("out.bias"), apply_sigmoid=True,
+                                        want_logits=want_logits, eps=BN_EPS)
             self.conv_bn(pl, st, f"d{i}", g, CONVT_K4S2, f, raw, ACT_RELU, cats[i - 1][..., :f],
                          drop_mask=mask, drop_rate=rate, drop_seed=seed * 16 + i, sample0=sample0)
             g = cats[i - 1]

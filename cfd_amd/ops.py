@@ -314,6 +314,34 @@ def convT_out(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], ap
     return (y, logits) if want_logits else y
 
 
+def convT_out_bn(raw: torch.Tensor, stats: Tuple[torch.Tensor, torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                 skip: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], apply_sigmoid: bool = True,
+                 want_logits: bool = False, eps: float = 1e-3):
+    """The output layer reading [ReLU(BN(raw)) | ReLU(skip)] without that tensor ever being written (inference).
+    raw: pre-BatchNorm output of the last decoder convolution (B,H,W,C1) with its per-sample sums `stats`; skip: the
+    first encoder activation (B,H,W,C2), possibly a channel slice of a wider buffer.  Same values as bn_apply (ReLU)
+    + convT_out(relu_on_load=True) on the concat buffer, bit for bit."""
+    B, Hi, Wi, c1 = raw.shape
+    c2 = skip.shape[-1]
+    _need(tuple(skip.shape) == (B, Hi, Wi, c2), f"skip is {tuple(skip.shape)}, raw {tuple(raw.shape)}")
+    _need(raw.dtype in (skip.dtype, torch.float32), f"raw {raw.dtype} with compute dtype {skip.dtype}")
+    rp, ldr = _nhwc(raw)
+    sp, lds = _nhwc(skip)
+    _numel(stats[0], B * c1, "stats sum", torch.float32)
+    _numel(stats[1], B * c1, "stats sumsq", torch.float32)
+    _numel(gamma, c1, "bn gamma", torch.float32)
+    _numel(beta, c1, "bn beta", torch.float32)
+    _numel(w, 16 * (c1 + c2), "convT_out weight", skip.dtype)
+    _numel(bias, 1, "convT_out bias", torch.float32)
+    taps = _workspace(B * Hi * Wi * 16 * 4, raw.device)
+    y = torch.empty((B, 2 * Hi, 2 * Wi, 1), dtype=torch.float32, device=raw.device)
+    logits = torch.empty_like(y) if want_logits else None
+    check(_lib.load().cfd_convT_out_bn(rp, ldr, _DT[raw.dtype], _ptr(stats[0]), _ptr(stats[1]), _ptr(gamma), _ptr(beta),
+                                       eps, sp, lds, _ptr(w), _ptr(bias), _ptr(taps), _ptr(y), _ptr(logits), B, Hi, Wi,
+                                       c1, c2, _DT[skip.dtype], int(apply_sigmoid), _stream()), "cfd_convT_out_bn")
+    return (y, logits) if want_logits else y
+
+
 def _bn_checks(x, out, out2, gamma, beta, drop_mask) -> None:
     shp, Cc = tuple(x.shape), x.shape[-1]
     _need(tuple(out.shape) == shp, f"bn out {tuple(out.shape)} != x {shp}")

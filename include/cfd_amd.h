@@ -140,6 +140,19 @@ int cfd_convT_out(const void *x, int ldx, const void *w, const float *bias, floa
 int cfd_convT_out_relu(const void *x, int ldx, const void *w, const float *bias, float *taps, float *y, float *logits,
                        int B, int Hi, int Wi, int Cin, int dtype, int apply_sigmoid, int relu_on_load, void *stream);
 
+/* The output layer with the LAST DECODER BLOCK's BatchNorm + ReLU applied as its operand is loaded (inference;
+ * generator.py:33-40 for d5 followed by :70-71): x[pixel] = [ReLU(BN(raw[pixel][0..C1))) | ReLU(skip[pixel][0..C2))].
+ * raw: pre-BatchNorm output of the last Conv2DTranspose, `raw_dtype` (fp32 is allowed under a bf16 compute dtype),
+ * [B][Hi][Wi][C1] stride ldraw; stat_sum / stat_sq: its per-sample sums [B][C1] (cfd_conv_forward_stats or cfd_bn_stats);
+ * gamma / beta / eps: the layer's BatchNorm; skip: `dtype` [B][Hi][Wi][C2] stride ldskip (the first encoder activation);
+ * w packed [1][4][4][C1 + C2].  Bit-identical to cfd_bn_apply(ReLU, no dropout) into a concat buffer followed by
+ * cfd_convT_out_relu -- minus one write and one read of the normalised tensor.  Hi * Wi must be a multiple of 16;
+ * built for C1 = C2 in {64, 128, 256}. */
+int cfd_convT_out_bn(const void *raw, int ldraw, int raw_dtype, const float *stat_sum, const float *stat_sq,
+                     const float *gamma, const float *beta, float eps, const void *skip, int ldskip, const void *w,
+                     const float *bias, float *taps, float *y, float *logits, int B, int Hi, int Wi, int C1, int C2,
+                     int dtype, int apply_sigmoid, void *stream);
+
 /* Conv2D 3x3 'same' on ONE input channel + bias + activation + MaxPooling2D(2,2) in one pass (inference path of
  * DeltaP/models/generator.py:23-26: g1 -> LeakyReLU -> pool).  x fp32 [B][Hi][Wi][1]; w fp32 packed [Cout][3][3][1];
  * y `out_dtype` dense [B][Hi/2][Wi/2][Cout].  act must be monotone (NONE / LEAKY with slope >= 0 / RELU): the maximum is

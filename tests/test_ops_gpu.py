@@ -250,6 +250,38 @@ def test_convT_out(cin, dtype):
     assert relerr(y.cpu(), torch.sigmoid(logits_ref)) <= 1e-4
 
 
+@pytest.mark.parametrize("dtype,raw_dtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                             (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 32, 256), (3, 4, 12, 128), (1, 32, 256, 64), (5, 16, 80, 128)])
+def test_convT_out_bn_equals_bn_apply_then_convT_out(B, H, W, C, dtype, raw_dtype):
+    """the output layer that normalises + rectifies its operand on load (inference) == cfd_bn_apply(ReLU) into the concat
+    buffer followed by cfd_convT_out_relu, BIT FOR BIT (same statistics buffer, same arithmetic, same MFMA chain), and
+    within tolerance of the oracle's BatchNorm -> ReLU -> Concatenate -> ReLU -> Conv2DTranspose (generator.py:33-40,70-71)"""
+    from cfd_amd import ops
+    dev = "cuda"
+    raw = (rnd((B, H, W, C), 1, 2.0) + 0.7).to(dev).to(raw_dtype)
+    cat = torch.zeros((B, H, W, 2 * C), dtype=dtype, device=dev)
+    cat[..., C:] = rnd((B, H, W, C), 2).to(dev).to(dtype)                 # the LeakyReLU'd first encoder activation
+    gamma, beta = (1.0 + rnd((C,), 3, 0.2)).to(dev), rnd((C,), 4, 0.2).to(dev)
+    wk = q(rnd((4, 4, 1, 2 * C), 5, 0.05), dtype)
+    wp = ops.pack_convT_weight(wk.to(dev), dtype)
+    bias = rnd((1,), 6, 0.1).to(dev)
+    st = (torch.zeros((B, C), device=dev), torch.zeros((B, C), device=dev))
+    ops.bn_stats(raw, st)
+    y1, l1 = ops.convT_out_bn(raw, st, gamma, beta, cat[..., C:], wp, bias, want_logits=True)
+    y1, l1 = y1.clone(), l1.clone()
+    ops.bn_apply(raw, st, gamma, beta, ops.ACT_RELU, out=cat[..., :C])
+    y0, l0 = ops.convT_out(cat, wp, bias, want_logits=True, relu_on_load=True)
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l0) and torch.equal(y1, y0)
+    r = raw.float().cpu()
+    mean, var = r.mean(dim=(1, 2), keepdim=True), r.var(dim=(1, 2), unbiased=False, keepdim=True)
+    act = torch.relu((r - mean) / torch.sqrt(var + 1e-3) * gamma.cpu() + beta.cpu())
+    xin = torch.cat([q(act, dtype), torch.relu(cat[..., C:].float().cpu())], dim=-1)
+    ref = O.conv2d_transpose_same(xin, wk, bias.cpu())
+    assert relerr(l1.cpu(), ref) <= (1e-4 if dtype == torch.float32 else 2e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,C,drop", [(2, 4, 32, 128, False), (3, 2, 16, 64, True), (1, 16, 128, 32, False)])
 def test_bn_act(B, H, W, C, drop, dtype):
