@@ -9,7 +9,8 @@ The reference's entry scripts touch their Keras models through a handful of name
   methods       .predict(x) .train_on_batch(x, y) .test_on_batch(x, y) .output_shape .layers .summary()
                 (U/train.py:41,121-125,148; utils.py:56; U/valid.py:29)
   persistence   save_model(model, path, overwrite=True, include_optimizer=True), load_model(path, compile=...)
-                (U/train.py:156,199-203,214-216; U/valid.py:39)
+                (U/train.py:156,199-203,214-216; U/valid.py:39): `.keras` zip archives with Keras 3's
+                `model.weights.h5` member (cfd_amd/h5.py, cfd_amd/keras_h5.py)
   losses        MC_mse, MC_mae, MC_huber_loss            U/models/loss.py
 
 Same names, same argument meaning, numpy NHWC fp32 in / numpy out, Python exceptions on error.
@@ -31,7 +32,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 import torch
 
-from . import nets, ops, trainer
+from . import h5, keras_h5, nets, ops, trainer
 
 
 def _dtype() -> torch.dtype:
@@ -414,12 +415,35 @@ def _load_opt(opt: trainer.Adam, z, prefix: str) -> None:
         opt.t = int(z[prefix + "t"][0])
 
 
+def _use_h5() -> bool:
+    """write `model.weights.h5` (Keras 3's member) when an HDF5 C library is present; CFD_AMD_KERAS_NPZ=1 keeps the
+    round-1 npz member instead"""
+    return os.environ.get("CFD_AMD_KERAS_NPZ", "0") != "1" and h5.available()
+
+
+def _opt_keras(params, opt: Optional[trainer.Adam]):
+    """(names, m, v) of one Adam range in `trainable_variables` order and Keras layouts"""
+    if opt is None:
+        return None
+    names = [n for n in keras_h5.trainable_order(params.specs) if opt.lo <= params.specs[n].offset < opt.hi]
+    return names, params.to_keras(opt.m, opt.lo, names), params.to_keras(opt.v, opt.lo, names)
+
+
+def _opt_from_keras(params, opt: trainer.Adam, t: int, m: dict, v: dict) -> None:
+    params.pack_keras(m, opt.m, opt.lo)
+    params.pack_keras(v, opt.v, opt.lo)
+    opt.t = int(t)
+
+
 def save_model(model, filepath, overwrite=True, include_optimizer=True):
     """Same call as keras.models.save_model; same file names (`*.keras`, a zip archive as in Keras 3).
-    Members: config.json, metadata.json (as Keras writes) and `model.weights.npz` holding the weights in KERAS
-    layouts (Conv2D (kh,kw,Cin,Cout), Conv2DTranspose (kh,kw,Cout,Cin), Dense (in,out)) plus `optimizer.npz`.
-    Keras itself stores the weights as HDF5 (`model.weights.h5`); h5py is not available in this environment, so
-    files are interchangeable with real Keras only through the npz member (documented in DESIGN.md)."""
+    Members: config.json, metadata.json and -- when the HDF5 C library is available (cfd_amd/h5.py) -- `model.weights.h5`
+    in Keras 3's own layout (cfd_amd/keras_h5.py: `layers/conv2d_3/vars/0`, ..., `optimizer/vars/<i>`; weights in KERAS
+    layouts: Conv2D (kh,kw,Cin,Cout), Conv2DTranspose (kh,kw,Cout,Cin), Dense (in,out)), so a Keras user can
+    `define_generator(...).load_weights(<that member>)`.  config.json is this library's own (the Keras model config is
+    not reproduced), so keras.models.load_model on these archives is not supported; load_model below reads both these
+    and archives Keras wrote.  Without HDF5 (or with CFD_AMD_KERAS_NPZ=1) the weights go to `model.weights.npz` +
+    `optimizer.npz` as in round 1."""
     filepath = str(filepath)
     if os.path.exists(filepath) and not overwrite:
         raise FileExistsError(filepath)
@@ -427,6 +451,8 @@ def save_model(model, filepath, overwrite=True, include_optimizer=True):
     cfg = {"format": FORMAT, "class_name": model.kind, "image_shape": list(model.image_shape),
            "compute_dtype": str(_dtype()).replace("torch.", "")}
     weights, opt = {}, {}
+    use_h5 = _use_h5()
+    h5sets, h5empty = {}, ["vars"]
     model.sync_state()
     if isinstance(model, DiscriminatorModel):
         cfg["d_freeze"] = getattr(model, "_d_freeze", None) or os.environ.get("CFD_AMD_D_FREEZE", "compile").lower()
@@ -435,37 +461,167 @@ def save_model(model, filepath, overwrite=True, include_optimizer=True):
         model.g_model.sync_state()
         model.d_model.sync_state()
         cfg["arch"] = model.g_model.arch
-        weights.update({"g/" + k: v for k, v in model.g_model.get_weights_dict().items()})
-        weights.update({"d/" + k: v for k, v in model.d_model.get_weights_dict().items()})
-        if include_optimizer:
-            opt.update(_opt_state(model._trainer.opt_g, "gan_g/"))
-            opt.update(_opt_state(model._trainer.opt_dbn, "gan_dbn/"))
+        tr = model._trainer
+        if use_h5:
+            for sub, pre in ((model.g_model, "layers/functional/"), (model.d_model, "layers/functional_1/")):
+                w = sub.get_weights_dict()
+                for n, path in keras_h5.weight_paths(sub.net.params.specs, pre).items():
+                    h5sets[path] = w[n]
+                h5empty.append(pre + "vars")
+            if include_optimizer:
+                h5sets.update(keras_h5.optimizer_datasets(
+                    [_opt_keras(model.g_model.net.params, tr.opt_g), _opt_keras(model.d_model.net.params, tr.opt_dbn)],
+                    tr.opt_g.t, tr.opt_g.lr))
+        else:
+            weights.update({"g/" + k: v for k, v in model.g_model.get_weights_dict().items()})
+            weights.update({"d/" + k: v for k, v in model.d_model.get_weights_dict().items()})
+            if include_optimizer:
+                opt.update(_opt_state(tr.opt_g, "gan_g/"))
+                opt.update(_opt_state(tr.opt_dbn, "gan_dbn/"))
     else:
         if isinstance(model, GeneratorModel):
             cfg["arch"] = model.arch
-        weights.update(model.get_weights_dict())
         tr = getattr(model, "_trainer", None)
-        if include_optimizer and tr is not None:
-            opt.update(_opt_state(tr.opt, "opt/"))
+        if use_h5:
+            w = model.get_weights_dict()
+            for n, path in keras_h5.weight_paths(model.net.params.specs).items():
+                h5sets[path] = w[n]
+            if include_optimizer and tr is not None:
+                h5sets.update(keras_h5.optimizer_datasets([_opt_keras(model.net.params, tr.opt)], tr.opt.t, tr.opt.lr))
+        else:
+            weights.update(model.get_weights_dict())
+            if include_optimizer and tr is not None:
+                opt.update(_opt_state(tr.opt, "opt/"))
     tmp = filepath + ".tmp"
-    with zipfile.ZipFile(tmp, "w", zipfile.ZIP_STORED) as z:
-        z.writestr("config.json", json.dumps(cfg))
-        z.writestr("metadata.json", json.dumps({"writer": "cfd_amd", "format": FORMAT}))
-        z.writestr("model.weights.npz", _npz_bytes(weights))
-        if opt:
-            z.writestr("optimizer.npz", _npz_bytes(opt))
+    tmp_h5 = filepath + ".weights.tmp.h5"
+    try:
+        with zipfile.ZipFile(tmp, "w", zipfile.ZIP_STORED) as z:
+            z.writestr("config.json", json.dumps(cfg))
+            z.writestr("metadata.json", json.dumps({"writer": "cfd_amd", "format": FORMAT}))
+            if use_h5:
+                h5.write(tmp_h5, h5sets, empty_groups=h5empty)
+                z.write(tmp_h5, "model.weights.h5")
+            else:
+                z.writestr("model.weights.npz", _npz_bytes(weights))
+                if opt:
+                    z.writestr("optimizer.npz", _npz_bytes(opt))
+    finally:
+        if os.path.exists(tmp_h5):
+            os.remove(tmp_h5)
     os.replace(tmp, filepath)
 
 
+def _keras_conv_flags(cfg) -> List[bool]:
+    """`trainable` of every Conv2D layer in a Keras model config"""
+    out: List[bool] = []
+    if isinstance(cfg, dict):
+        if cfg.get("class_name") == "Conv2D" and isinstance(cfg.get("config"), dict):
+            out.append(bool(cfg["config"].get("trainable", True)))
+        for v in cfg.values():
+            out += _keras_conv_flags(v)
+    elif isinstance(cfg, list):
+        for v in cfg:
+            out += _keras_conv_flags(v)
+    return out
+
+
+def _load_h5_archive(z: zipfile.ZipFile, cfg: dict, ours: bool, compile: bool, filepath: str):
+    """a `.keras` archive whose weights are Keras 3's `model.weights.h5`: ours, or one Keras itself wrote"""
+    if not h5.available():
+        raise NotImplementedError("this archive stores its weights as HDF5 (`model.weights.h5`) and no HDF5 C library "
+                                  "was found: set CFD_AMD_HDF5 to a libhdf5.so (cfd_amd/h5.py)")
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".h5", dir=os.path.dirname(os.path.abspath(filepath))) as tf:
+        with z.open("model.weights.h5") as src:
+            while True:
+                blk = src.read(1 << 24)
+                if not blk:
+                    break
+                tf.write(blk)
+        tf.flush()
+        data, _groups = h5.read(tf.name)
+    firsts = {a["enc"][0]: name for name, a in nets.GEN_ARCH.items()}
+    if ours:
+        kind, arch, shape = cfg["class_name"], cfg.get("arch"), tuple(cfg["image_shape"])
+    else:
+        kind, arch, _ = keras_h5.classify(data, firsts)
+        shape = keras_h5.input_shape_from_config(cfg) or (64, 512, 1)
+    ovars = keras_h5.optimizer_vars(data) if compile else []
+
+    def fill(m, prefix=""):
+        specs = m.net.params.specs
+        m.set_weights_dict(keras_h5.pick(data, keras_h5.weight_paths(specs, prefix), specs))
+
+    if kind == "generator":
+        m = GeneratorModel(arch, shape)
+        fill(m)
+    elif kind == "cnn":
+        m = CnnModel(shape)
+        fill(m)
+        st = keras_h5.split_optimizer(ovars, keras_h5.trainable_order(m.net.params.specs)) if ovars else None
+        if st:
+            _opt_from_keras(m.net.params, m._tr().opt, *st)
+    elif kind == "discriminator":
+        m = DiscriminatorModel(shape)
+        fill(m)
+        specs = m.net.params.specs
+        if ours:
+            frozen = not cfg.get("d_convs_trainable", True)
+            mode = cfg.get("d_freeze")
+        else:
+            flags = _keras_conv_flags(cfg)
+            frozen = bool(flags) and not any(flags)
+            # an optimizer that holds BatchNorm variables only was built AFTER define_gan froze the convolutions: the
+            # archive's writer read `trainable` at call time (keras_api.DiscriminatorModel.d_step_trains_convs)
+            n_all, n_bn = len(keras_h5.trainable_order(specs)), len(keras_h5.trainable_order(specs, convs=False))
+            mode = {2 + 2 * n_all: "compile", 2 + 2 * n_bn: "call"}.get(len(ovars)) if ovars else None
+        if mode:
+            m._d_freeze = mode
+        if frozen:
+            for l in m.layers:
+                if not isinstance(l, BatchNormalization):
+                    l.trainable = False
+        if ovars:
+            opt = m._tr().opt
+            names = [n for n in keras_h5.trainable_order(specs) if opt.lo <= specs[n].offset < opt.hi]
+            st = keras_h5.split_optimizer(ovars, names)
+            if st:
+                _opt_from_keras(m.net.params, opt, *st)
+    elif kind == "gan":
+        g, d = GeneratorModel(arch, shape), DiscriminatorModel(shape)
+        fill(g, "layers/functional/")
+        fill(d, "layers/functional_1/")
+        m = define_gan(g, d, shape)
+        if ovars:
+            ng = keras_h5.trainable_order(g.net.params.specs)
+            nd = keras_h5.trainable_order(d.net.params.specs, convs=False)
+            st = keras_h5.split_optimizer(ovars, ng + nd)
+            if st:
+                t, mm, vv = st
+                # (the names of the two nets overlap -- c2.bn.gamma vs e2.bn.gamma do not, but keep them apart anyway)
+                k = 2 + 2 * len(ng)
+                sg = keras_h5.split_optimizer(ovars[:k], ng)
+                sd = keras_h5.split_optimizer(ovars[:2] + ovars[k:], nd)
+                _opt_from_keras(g.net.params, m._trainer.opt_g, *sg)
+                _opt_from_keras(d.net.params, m._trainer.opt_dbn, *sd)
+    else:
+        raise ValueError(f"unknown model class {kind}")
+    return m
+
+
 def load_model(filepath, compile=True, custom_objects=None):
-    """keras.models.load_model counterpart for archives written by save_model above."""
-    with zipfile.ZipFile(str(filepath)) as z:
+    """keras.models.load_model counterpart: reads the archives save_model above writes (HDF5 or npz member) AND `.keras`
+    archives written by Keras 3 itself for the four reference graphs (U/train.py:198-203): the graph is recognised from
+    the shapes in `model.weights.h5`, the image shape from the InputLayer in Keras' config.json, the optimizer state
+    from `optimizer/vars/*` (compile=True).  custom_objects (the MC_* losses) is accepted and not needed."""
+    filepath = str(filepath)
+    with zipfile.ZipFile(filepath) as z:
         names = set(z.namelist())
         cfg = json.loads(z.read("config.json"))
-        if cfg.get("format") != FORMAT:
-            if "model.weights.h5" in names:
-                raise NotImplementedError("this is a real Keras HDF5 archive; reading it needs h5py, which is not "
-                                          "installed here (SURVEY.md §8(b))")
+        ours = isinstance(cfg, dict) and cfg.get("format") == FORMAT
+        if "model.weights.h5" in names:
+            return _load_h5_archive(z, cfg, ours, compile, filepath)
+        if not ours:
             raise ValueError(f"unknown archive format in {filepath}")
         w = dict(np.load(io.BytesIO(z.read("model.weights.npz")), allow_pickle=False))
         o = dict(np.load(io.BytesIO(z.read("optimizer.npz")), allow_pickle=False)) if "optimizer.npz" in names else {}

@@ -189,12 +189,15 @@ class ParamStore:
                 self.m(name).copy_(src)
         self.refresh_compute()
 
-    def to_keras(self) -> Dict[str, np.ndarray]:
+    def to_keras(self, flat: torch.Tensor = None, base: int = 0, names=None) -> Dict[str, np.ndarray]:
         """checkpoint / test export in Keras layouts.  The layout change runs on the device (a strided host transpose
-        of the 128 M-parameter generator took 2 s per save: the training script's wall time was its checkpoints)."""
+        of the 128 M-parameter generator took 2 s per save: the training script's wall time was its checkpoints).
+        flat / base: any flat buffer laid out like the master from offset `base` on (Adam's m and v); names: a subset."""
         out = {}
-        for name, s in self.specs.items():
-            a = self.master[s.offset:s.offset + s.numel].view(s.packed_shape)
+        src = self.master if flat is None else flat
+        for name in (self.specs if names is None else names):
+            s = self.specs[name]
+            a = src[s.offset - base:s.offset - base + s.numel].view(s.packed_shape)
             if s.kind == "conv":       # [co][kh][kw][ci] -> (kh,kw,ci,co)
                 a = a.permute(1, 2, 3, 0)
             elif s.kind == "convT":    # [co][kh][kw][ci] -> (kh,kw,co,ci)
@@ -203,6 +206,25 @@ class ParamStore:
                 a = a.permute(1, 0)
             out[name] = a.contiguous().cpu().numpy()
         return out
+
+    def pack_keras(self, weights: Dict[str, np.ndarray], flat: torch.Tensor, base: int = 0) -> None:
+        """Keras-layout arrays -> their packed places in `flat` (laid out like the master from offset `base` on):
+        Adam moments of an imported checkpoint.  Only the names given are written."""
+        for name, w in weights.items():
+            s = self.specs[name]
+            w = np.ascontiguousarray(np.asarray(w, dtype=np.float32))
+            if tuple(w.shape) != s.keras_shape:
+                raise ValueError(f"{name}: expected Keras shape {s.keras_shape}, got {w.shape}")
+            src = torch.from_numpy(w).to(self.device)
+            dst = flat[s.offset - base:s.offset - base + s.numel].view(s.packed_shape)
+            if s.kind == "conv":
+                dst.copy_(ops.pack_conv_weight(src, torch.float32))
+            elif s.kind == "convT":
+                dst.copy_(ops.pack_convT_weight(src, torch.float32))
+            elif s.kind == "dense":
+                dst.copy_(ops.pack_dense_weight(src, torch.float32))
+            else:
+                dst.copy_(src)
 
     def init_random_normal(self, seed: int, stddev: float = 0.02) -> None:
         """RandomNormal(stddev=0.02) kernels, zero biases, BN gamma=1 beta=0, moving mean 0 var 1

@@ -180,3 +180,96 @@ def test_discriminator_own_step_freeze_switch(mode, monkeypatch):
     k1 = P.m("c3.kernel").clone()
     gan.train_on_batch([x], [np.ones((1, 4, 32, 1)), u])
     assert bool((P.m("c3.kernel") == k1).all())
+
+
+def _keras_style_archive(path, datasets, image_shape, empty=()):
+    """a `.keras` archive laid out the way Keras 3 writes it (config.json = a Functional model config, metadata.json,
+    model.weights.h5) -- built by hand: Keras is not installed, so this is the published layout, not Keras' own output"""
+    import json
+    import zipfile
+    from cfd_amd import h5
+    tmp = str(path) + ".h5"
+    h5.write(tmp, datasets, empty_groups=("vars",) + tuple(empty))
+    cfg = {"module": "keras", "class_name": "Functional", "registered_name": "Functional",
+           "config": {"name": "functional", "trainable": True, "layers": [
+               {"module": "keras.layers", "class_name": "InputLayer", "registered_name": None,
+                "config": {"batch_shape": [None] + list(image_shape), "dtype": "float32", "sparse": False, "name": "input_layer"}}]}}
+    with zipfile.ZipFile(str(path), "w") as z:
+        z.writestr("metadata.json", json.dumps({"keras_version": "3.3.3", "date_saved": "2024-06-01@00:00:00"}))
+        z.writestr("config.json", json.dumps(cfg))
+        z.write(tmp, "model.weights.h5")
+    os.remove(tmp)
+
+
+def test_load_model_reads_keras3_archives(tmp_path, monkeypatch):
+    """`.keras` archives as Keras 3 lays them out (zip + model.weights.h5 with
+    layers/<class>_<k>/vars/<i> and optimizer/vars/<i>) load into the HIP nets: graph recognised from the shapes, image
+    shape from the InputLayer, weights and Adam state placed by Keras' variable order.  And save_model writes that same
+    member, so its weights file is what `model.load_weights` of real Keras expects."""
+    import zipfile
+    from cfd_amd import h5, keras_api as K, keras_h5
+    if not h5.available():
+        pytest.skip("no HDF5 C library")
+    monkeypatch.setenv("CFD_AMD_DTYPE", "fp32")
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 64, 512, 1)).astype("float32")
+    # ---- DeltaP CNN with optimizer state: train two steps, hand the state over in Keras' layout, continue on both
+    a = K.define_cnn_model((64, 512, 1))
+    y = rng.standard_normal((2, 1)).astype("float32")
+    for _ in range(2):
+        a.train_on_batch(x, y)
+    specs = a.net.params.specs
+    w = a.get_weights_dict()
+    ds = {path: w[n] for n, path in keras_h5.weight_paths(specs).items()}
+    names, m, v = K._opt_keras(a.net.params, a._tr().opt)
+    assert names == keras_h5.trainable_order(specs)
+    ds.update(keras_h5.optimizer_datasets([(names, m, v)], a._tr().opt.t, 1e-3))
+    _keras_style_archive(tmp_path / "cnn.keras", ds, (64, 512, 1),
+                         empty=("layers/input_layer/vars", "layers/leaky_re_lu/vars", "layers/max_pooling2d/vars",
+                                "layers/flatten/vars", "layers/dropout/vars"))
+    b = K.load_model(str(tmp_path / "cnn.keras"))
+    assert isinstance(b, K.CnnModel) and b.image_shape == (64, 512, 1)
+    wb = b.get_weights_dict()
+    assert all(np.array_equal(w[k], wb[k]) for k in w)
+    assert b._tr().opt.t == 2
+    b._seed = a._seed                                                   # same dropout draw in the next step
+    la, lb = a.train_on_batch(x, y), b.train_on_batch(x, y)
+    assert np.allclose(la, lb, rtol=1e-5, atol=1e-6), (la, lb)
+    # same weights AND same Adam moments -> the same third update
+    wa, wb = a.get_weights_dict(), b.get_weights_dict()
+    assert all(np.allclose(wa[k], wb[k], rtol=1e-5, atol=1e-7) for k in wa)
+    # ---- P generator (no optimizer), 128 x 1024 image: shape comes from Keras' config
+    g = K.define_generator_P((128, 1024, 1))
+    wg = g.get_weights_dict()
+    _keras_style_archive(tmp_path / "g.keras", {p: wg[n] for n, p in keras_h5.weight_paths(g.net.params.specs).items()},
+                         (128, 1024, 1))
+    g2 = K.load_model(str(tmp_path / "g.keras"), compile=False)
+    assert isinstance(g2, K.GeneratorModel) and g2.arch == "P" and g2.image_shape == (128, 1024, 1)
+    wg2 = g2.get_weights_dict()
+    assert all(np.array_equal(wg[k], wg2[k]) for k in wg)
+    # ---- discriminator whose optimizer holds BatchNorm variables only: written by a Keras that read `trainable` at call time
+    d = K.define_discriminator((64, 512, 1))
+    sd = d.net.params.specs
+    wd = d.get_weights_dict()
+    ds = {p: wd[n] for n, p in keras_h5.weight_paths(sd).items()}
+    bn = keras_h5.trainable_order(sd, convs=False)
+    ds.update(keras_h5.optimizer_datasets([(bn, {n: 0.25 * np.ones(sd[n].keras_shape, "float32") for n in bn},
+                                            {n: 0.5 * np.ones(sd[n].keras_shape, "float32") for n in bn})], 7, 2e-3))
+    _keras_style_archive(tmp_path / "d.keras", ds, (64, 512, 1))
+    d2 = K.load_model(str(tmp_path / "d.keras"))
+    assert d2._d_freeze == "call" and all(np.array_equal(wd[k], d2.get_weights_dict()[k]) for k in wd)
+    # ---- what save_model writes is that same member
+    K.save_model(a, str(tmp_path / "ours.keras"))
+    with zipfile.ZipFile(str(tmp_path / "ours.keras")) as z:
+        assert "model.weights.h5" in z.namelist() and "model.weights.npz" not in z.namelist()
+        z.extract("model.weights.h5", str(tmp_path))
+    data, groups = h5.read(str(tmp_path / "model.weights.h5"))
+    assert np.array_equal(data["layers/dense/vars/0"], wa["fc1.kernel"]) and data["layers/dense/vars/0"].shape == (8 * 64 * 512, 256)
+    assert int(data["optimizer/vars/0"]) == 3 and "vars" in groups
+    c = K.load_model(str(tmp_path / "ours.keras"))
+    assert c._tr().opt.t == 3 and all(np.array_equal(wa[k], c.get_weights_dict()[k]) for k in wa)
+    # the npz member of round 1 still loads
+    monkeypatch.setenv("CFD_AMD_KERAS_NPZ", "1")
+    K.save_model(a, str(tmp_path / "npz.keras"))
+    e = K.load_model(str(tmp_path / "npz.keras"))
+    assert e._tr().opt.t == 3 and all(np.array_equal(wa[k], e.get_weights_dict()[k]) for k in wa)
