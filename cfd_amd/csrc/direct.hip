@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256) void tapgemm_bn_bf16_kernel(const TR *__restri
                                                              const bf16 *__restrict__ w, float *__restrict__ taps, int HW,
                                                              int chunks, int pix_per_chunk) {
   constexpr int CIN = C1 + C2, S1 = C1 / 64, S2 = C2 / 64;
+  constexpr int G1 = S1 % 2 == 0 ? 2 : 1, G2 = S2 % 2 == 0 ? 2 : 1;   // 64-channel steps handled together
   __shared__ __align__(16) float s_sc[C1], s_sh[C1];
   const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
   bn_coeffs_to_lds<C1>(s_sc, s_sh, ssum, ssq, gamma, beta, eps, b, HW);
@@ -370,34 +371,51 @@ __global__ __launch_bounds__(256) void tapgemm_bn_bf16_kernel(const TR *__restri
     const size_t pix = (size_t)b * HW + pt + fr;
     const TR *rp = raw + pix * ldraw + fq * 16;
     const bf16 *sp = skip + pix * ldskip + fq * 16;
-    bf16x8 xa[S1 + S2][2];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // two 64-channel steps at a time, each group's loads, conversion and MFMAs kept together (sched_barrier): with every
+    // load of a pixel row hoisted to the top the kernel needed 296 registers, i.e. ONE wave per SIMD for an HBM-bound loop
 #pragma unroll
-    for (int s = 0; s < S2; ++s) {
-      xa[S1 + s][0] = relu8(*(const bf16x8 *)(sp + s * 64));
-      xa[S1 + s][1] = relu8(*(const bf16x8 *)(sp + s * 64 + 8));
+    for (int s0 = 0; s0 < S1; s0 += G1) {
+      bf16x8 xa[G1][2];
+#pragma unroll
+      for (int ds = 0; ds < G1; ++ds)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int s = s0 + ds;
+          float f[8];
+          load8<TR>(rp + s * 64 + h * 8, f);
+          const int c = s * 64 + fq * 16 + h * 8;
+          const f32x4 a0 = *(const f32x4 *)&s_sc[c], a1 = *(const f32x4 *)&s_sc[c + 4];
+          const f32x4 b0 = *(const f32x4 *)&s_sh[c], b1 = *(const f32x4 *)&s_sh[c + 4];
+          bf16x8 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            o[i] = (bf16)apply_act_linear(fmaf(f[i], a0[i], b0[i]), 0.f);
+            o[4 + i] = (bf16)apply_act_linear(fmaf(f[4 + i], a1[i], b1[i]), 0.f);
+          }
+          xa[ds][h] = o;
+        }
+#pragma unroll
+      for (int ds = 0; ds < G1; ++ds) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s0 + ds][0], xa[ds][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s0 + ds][1], xa[ds][1], acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int s = 0; s < S1; ++s)
+    for (int s0 = 0; s0 < S2; s0 += G2) {
+      bf16x8 xa[G2][2];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float f[8];
-        load8<TR>(rp + s * 64 + h * 8, f);
-        const int c = s * 64 + fq * 16 + h * 8;
-        const f32x4 a0 = *(const f32x4 *)&s_sc[c], a1 = *(const f32x4 *)&s_sc[c + 4];
-        const f32x4 b0 = *(const f32x4 *)&s_sh[c], b1 = *(const f32x4 *)&s_sh[c + 4];
-        bf16x8 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          o[i] = (bf16)apply_act_linear(fmaf(f[i], a0[i], b0[i]), 0.f);
-          o[4 + i] = (bf16)apply_act_linear(fmaf(f[4 + i], a1[i], b1[i]), 0.f);
-        }
-        xa[s][h] = o;
+      for (int ds = 0; ds < G2; ++ds) {
+        xa[ds][0] = relu8(*(const bf16x8 *)(sp + (s0 + ds) * 64));
+        xa[ds][1] = relu8(*(const bf16x8 *)(sp + (s0 + ds) * 64 + 8));
       }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < S1 + S2; ++s) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][0], xa[s][0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][1], xa[s][1], acc, 0, 0, 0);
+      for (int ds = 0; ds < G2; ++ds) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[S1 + s0 + ds][0], xa[ds][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[S1 + s0 + ds][1], xa[ds][1], acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     *(f32x4 *)(taps + pix * 16 + fq * 4) = acc;
   }
@@ -452,6 +470,7 @@ __global__ __launch_bounds__(256) void tapgemm_bn_f32_kernel(const float *__rest
       for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][0][e], a[0][e], acc, 0, 0, 0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][1][e], a[1][e], acc, 0, 0, 0);
+      if (s & 1) __builtin_amdgcn_sched_barrier(0);   // (keeps the loads of at most two steps in flight per wave: registers)
     }
     *(f32x4 *)(taps + pix * 16 + fq * 4) = acc;
   }
