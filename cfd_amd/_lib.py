@@ -101,14 +101,17 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise CfdError(f"{LIB_PATH} is missing: build it with `python -m cfd_amd.build` "
+    # CFD_AMD_LIB=<file>: another build of the SAME library (scripts/build_variant.sh: an earlier commit's kernels, for
+    # interleaved A/B runs on one box); still the HIP library, still no fallback
+    path = os.environ.get("CFD_AMD_LIB") or LIB_PATH
+    if not os.path.exists(path):
+        raise CfdError(f"{path} is missing: build it with `python -m cfd_amd.build` "
                        "(the HIP library is the only compute path; there is no fallback)")
     # torch ships its own libamdhip64; import it FIRST so that this library binds to the same HIP
     # runtime (same soname) instead of pulling a second copy from /opt/rocm -- two runtimes in one
     # process do not share devices, streams or allocations.
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
