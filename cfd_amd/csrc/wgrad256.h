@@ -18,6 +18,7 @@ struct Wgrad256Params {
   int cotiles, citiles, split_m, nblocks;
   unsigned pbytes, gbytes, margin;
   int gather_a;               // 1: the co-side operand (dY) is the gathered one (transposed conv)
+  int pair, tap_groups;       // pair = 1: a tile's 256 ci columns are two adjacent taps x 128 channels; blocks per (co, ci) tile
 };
 
 bool wgrad256_plan(const cfd_conv_desc *d, Wgrad256Params &p);

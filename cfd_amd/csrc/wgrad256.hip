@@ -46,7 +46,10 @@ __device__ __forceinline__ bf16x8 tr_read2(const char *lds, unsigned o0, unsigne
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <bool GATHER_A>
+// PAIR (conv kinds with Cin == 128 and an even kernel width, e.g. the discriminator's c2): the 256 ci columns of a tile are
+// TWO horizontally adjacent taps x 128 channels -- B0 = tap t, B1 = tap t + 1 (the same 128 channels one input pixel to the
+// right, with its own in-image test); dW's [tap][ci] columns are contiguous, so the epilogue is unchanged.
+template <bool GATHER_A, bool PAIR>
 __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x;
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
     const int nwg = p.nblocks, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tap = bid % p.ntaps; bid /= p.ntaps;
+  const int tap = (bid % p.tap_groups) * (PAIR ? 2 : 1); bid /= p.tap_groups;
   const int cit = bid % p.citiles; bid /= p.citiles;
   const int cot = bid % p.cotiles;
   const int sm = bid / p.cotiles;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
   // 8 + w: rows R_i = (i*8 + w)*4 + lane/16, physical 16-B slot lane%16 holding LOGICAL chunk slot ^ (R & 15)
   const int lrow = lane >> 4, slot = lane & 15;
   const int cplain = GATHER_A ? ci0 : co0, cgath = GATHER_A ? co0 : ci0;
-  unsigned pv[2], gl[2], cur[2];
+  unsigned pv[2], gl[2], cur[2], cur1[2];
   int gyl[2], gxl[2];
   const int Wm_mask = (1 << p.lw) - 1, Hm_mask = (1 << p.lh) - 1;
 #pragma unroll
@@ -105,8 +108,9 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
     s_g = (unsigned)(((bs * p.Hg + gys) * p.Wg + gxs) * p.ldg * 2);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const bool ok = (unsigned)(gyl[i] + gys) < (unsigned)p.Hg && (unsigned)(gxl[i] + gxs) < (unsigned)p.Wg;
-      cur[i] = ok ? gl[i] : WOOB;
+      const bool oky = (unsigned)(gyl[i] + gys) < (unsigned)p.Hg;
+      cur[i] = oky && (unsigned)(gxl[i] + gxs) < (unsigned)p.Wg ? gl[i] : WOOB;
+      if (PAIR) cur1[i] = oky && (unsigned)(gxl[i] + gxs + 1) < (unsigned)p.Wg ? gl[i] + (unsigned)(p.ldg * 2) : WOOB;
     }
   };
   auto iss_advance = [&]() {
@@ -119,7 +123,9 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
     char *dst = ldsw + wslot_off(stage, sl);
     const bool is_a = (sl == 0 || sl == 3);
     const unsigned half = (sl == 2 || sl == 3) ? 256u : 0u;
-    if (is_a == GATHER_A) {
+    if (PAIR && sl == 2) {
+      wbload16(grs, cur1[0], s_g, dst); wbload16(grs, cur1[1], s_g, dst + 8192);
+    } else if (is_a == GATHER_A) {
       wbload16(grs, cur[0], s_g + half, dst); wbload16(grs, cur[1], s_g + half, dst + 8192);
     } else {
       wbload16(prs, pv[0], s_p + half, dst); wbload16(prs, pv[1], s_p + half, dst + 8192);
@@ -257,7 +263,8 @@ static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // fills `p` (without pointers) and returns true when the 256x256 kernel can run this layer
 bool wgrad256_plan(const cfd_conv_desc *d, Wgrad256Params &p) {
   memset(&p, 0, sizeof(p));
-  if (d->dtype != CFD_BF16 || d->Cin % 256 || d->Cout % 256) return false;
+  const bool pair = d->Cin == 128 && (d->kind == CFD_CONV_K4S2 || d->kind == CFD_CONV_K4S1);
+  if (d->dtype != CFD_BF16 || (d->Cin % 256 && !pair) || d->Cout % 256) return false;
   int Hy, Wy, Hm, Wm;
   switch (d->kind) {
     case CFD_CONV_K4S2: Hy = d->Hi / 2; Wy = d->Wi / 2; p.ntaps = 16; p.ktaps_w = 4; p.S = 2; p.oy_base = -1; p.ox_base = -1; Hm = Hy; Wm = Wy; break;
@@ -289,12 +296,14 @@ bool wgrad256_plan(const cfd_conv_desc *d, Wgrad256Params &p) {
   const int64_t slack = (int64_t)64 * (p.ldp > p.ldg ? p.ldp : p.ldg) * 2 * 4 + margin * 4;
   if (pb + slack >= (1LL << 31) || gb + margin + slack >= (1LL << 31)) return false;
   p.pbytes = (unsigned)pb; p.gbytes = (unsigned)(gb + margin); p.margin = (unsigned)margin;
-  p.cotiles = d->Cout / 256; p.citiles = d->Cin / 256;
+  p.pair = pair;
+  p.cotiles = d->Cout / 256; p.citiles = pair ? 1 : d->Cin / 256;
+  p.tap_groups = pair ? p.ntaps / 2 : p.ntaps;
   return true;
 }
 
 int wgrad256_suggest_split(const Wgrad256Params &p) {
-  const int tiles = p.cotiles * p.citiles * p.ntaps;
+  const int tiles = p.cotiles * p.citiles * p.tap_groups;
   const int ktiles = (p.M + 63) / 64;
   int s = 1;
   while (tiles * s * 2 <= 512 && ktiles / (s * 2) >= 16) s *= 2;
@@ -322,19 +331,22 @@ int wgrad256_launch(Wgrad256Params &p, const void *x, const void *dy, float *dw,
   const int ktiles = (p.M + 63) / 64;
   p.split_m = split_m < ktiles ? split_m : ktiles;
   CFD_REQUIRE((int64_t)ktiles * p.split_m < (1LL << 31), "reduction too long for 32-bit slice arithmetic");
-  p.nblocks = p.cotiles * p.citiles * p.ntaps * p.split_m;
+  p.nblocks = p.cotiles * p.citiles * p.tap_groups * p.split_m;
   p.dw_elems = (int64_t)p.Cout * p.ntaps * p.Cin;
   CFD_REQUIRE(p.dw_elems < (1LL << 31), "weight tensor too large for 32-bit element offsets");
   p.slab = p.split_m > 1 ? workspace : nullptr;
   const size_t shmem = 2 * WST;
   static bool done = false;
   if (!done) {
-    CFD_HIP(hipFuncSetAttribute((const void *)wgrad256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    CFD_HIP(hipFuncSetAttribute((const void *)wgrad256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    CFD_HIP(hipFuncSetAttribute((const void *)wgrad256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    CFD_HIP(hipFuncSetAttribute((const void *)wgrad256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    CFD_HIP(hipFuncSetAttribute((const void *)wgrad256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     done = true;
   }
-  if (p.gather_a) hipLaunchKernelGGL(wgrad256_kernel<true>, dim3(p.nblocks), dim3(512), shmem, st, p);
-  else hipLaunchKernelGGL(wgrad256_kernel<false>, dim3(p.nblocks), dim3(512), shmem, st, p);
+  CFD_REQUIRE(!(p.pair && p.gather_a), "tap pairs need a gathered ci-side operand");
+  if (p.gather_a) hipLaunchKernelGGL((wgrad256_kernel<true, false>), dim3(p.nblocks), dim3(512), shmem, st, p);
+  else if (p.pair) hipLaunchKernelGGL((wgrad256_kernel<false, true>), dim3(p.nblocks), dim3(512), shmem, st, p);
+  else hipLaunchKernelGGL((wgrad256_kernel<false, false>), dim3(p.nblocks), dim3(512), shmem, st, p);
   CFD_LAUNCH_CHECK();
   if (p.slab) {
     const int64_t n4 = p.dw_elems / 4;

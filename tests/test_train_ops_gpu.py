@@ -101,6 +101,9 @@ WG256 = [
     ("convT", 2, 8, 16, 256, 256, 2),    # gathered operand = dY (co side)
     ("convT", 1, 1, 8, 512, 256, 1),     # M = 8 < one K tile: ragged tail rows must read as zero
     ("dense", 70, 1, 1, 256, 256, 1),    # 1x1 grid, M = 70 (ragged)
+    ("k4s2", 2, 16, 32, 128, 256, 1),    # Cin = 128: a tile's ci columns are two adjacent taps (the discriminator's c2)
+    ("k4s2", 3, 8, 128, 128, 512, 3),    # the same with a ragged split and one grid row per K tile
+    ("k4s1", 2, 4, 32, 128, 256, 2),     # stride 1, asymmetric padding: the second tap of a pair leaves the image on the right
 ]
 
 
