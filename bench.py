@@ -95,6 +95,9 @@ def build_nets(names, tdt):
     return out
 
 
+SYNC3 = os.environ.get("CFD_BENCH_SYNC3", "0") == "1"     # A/B: read every loss at its own call (three host syncs per step)
+
+
 class TrainJob:
     def __init__(self, tdt):
         from cfd_amd import nets, trainer
@@ -102,17 +105,20 @@ class TrainJob:
         self.d = nets.Discriminator(dtype=tdt, seed=8)
         self.dtr = trainer.DiscriminatorTrainer(self.d)
         self.gtr = trainer.GanTrainer(self.g, self.d)
+        self.dloss = torch.zeros(2, dtype=torch.float32, device="cuda")
 
     def step(self, x, y, step, sample0):
         """The reference's four calls (U/train.py:119-125).  The generator's forwards do not read D's weights, so
         they are enqueued between a D update's all-reduce launch and its Adam step: same arithmetic as the
-        reference's order, with D's gradient exchange hidden behind them when world > 1."""
-        self.dtr.begin(x, y, 1.0)                                         # d_model.train_on_batch([A,B], ones) ...
+        reference's order, with D's gradient exchange hidden behind them when world > 1.  The three losses are read
+        once, after the third call (the reference only logs them): one host sync per step instead of three."""
+        self.dtr.begin(x, y, 1.0, loss=self.dloss[0:1])                   # d_model.train_on_batch([A,B], ones) ...
         fake = self.g.forward(x, seed=2 * step, sample0=sample0, inference=True)   # generate_fake_samples (utils.py:52-62)
-        self.dtr.finish()                                                 # ... its all-reduce, Adam
-        self.dtr.begin(x, fake, 0.0)                                      # d_model.train_on_batch([A,fake], zeros)
-        return self.gtr.train_on_batch(x, 1.0, y, seed=2 * step + 1, sample0=sample0,
-                                       before_d=self.dtr.finish)          # gan_model.train_on_batch
+        self.dtr.finish(sync=SYNC3)                                       # ... its all-reduce, Adam
+        self.dtr.begin(x, fake, 0.0, loss=self.dloss[1:2])                # d_model.train_on_batch([A,fake], zeros)
+        out = self.gtr.train_on_batch(x, 1.0, y, seed=2 * step + 1, sample0=sample0,
+                                      before_d=lambda: self.dtr.finish(sync=SYNC3))        # gan_model.train_on_batch
+        return self.dloss.tolist() + out
 
 
 def run_step(models, x, step, sample0):

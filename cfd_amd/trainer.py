@@ -344,6 +344,7 @@ class DiscriminatorTrainer:
         self.dp = _DP()
         sync_from_rank0(self.dp, d.params, [self.opt])
         self.loss = torch.zeros(1, dtype=torch.float32, device=d.device)
+        self._loss_out = self.loss
         self._pending = None
 
     def sync_state(self) -> None:
@@ -354,25 +355,29 @@ class DiscriminatorTrainer:
         self.begin(src, tgt, label)
         return self.finish()
 
-    def begin(self, src: torch.Tensor, tgt: torch.Tensor, label: float) -> None:
+    def begin(self, src: torch.Tensor, tgt: torch.Tensor, label: float, loss: Optional[torch.Tensor] = None) -> None:
         """forward + backward + launch of the gradient all-reduce.  Work that does not read D's weights (the
         generator's forward) may be enqueued between begin() and finish(): it then overlaps the collective, which
-        D's short backward cannot hide by itself."""
+        D's short backward cannot hide by itself.  `loss`: a 1-element fp32 device tensor that receives this update's loss
+        instead of the trainer's own (a training loop that reads its three losses once per step, see finish(sync=False))."""
         d, P = self.d, self.d.params
         B = src.shape[0]
         P.zero_grad()
-        self.loss.zero_()
+        self._loss_out = self.loss if loss is None else loss
+        self._loss_out.zero_()
         logits = d.forward(src, tgt, training=True, want_logits=True)
         dz = d.buf(d.plan(B), "dlogits", logits.shape, torch.float32)
-        ops.bce_logits(logits, self.loss, dz, target_const=label)
+        ops.bce_logits(logits, self._loss_out, dz, target_const=label)
         d.backward(dz, src, tgt, train_convs=self.train_convs, side_wgrad=_side_wgrad(self.dp))
         if self.opt.lo < P.n_main:
             self.dp.reduce_range_async(P, self.opt.lo, P.n_main)
         self.dp.reduce_range_async(P, max(self.opt.lo, P.n_main), self.opt.hi)
         self._pending = B
 
-    def finish(self) -> float:
-        """wait for the all-reduce, Adam, moving statistics; returns the loss (one host sync)"""
+    def finish(self, sync: bool = True):
+        """wait for the all-reduce, Adam, moving statistics; returns the loss (one host sync), or -- sync=False -- the
+        device tensor that will hold it, without waiting: U/train.py:121-125 uses the three losses of a step only after
+        its third call, and every host sync drains the GPU's queue (three per step cost 1-2 % at batch 16)"""
         B, self._pending = self._pending, None
         if B is None:
             raise RuntimeError("finish() without begin()")
@@ -386,7 +391,7 @@ class DiscriminatorTrainer:
         join_averages()
         self.d.update_moving(B)
         self.dp.average_async(P.master[P.n_trainable:P.n_total])
-        return float(self.loss.item())
+        return float(self._loss_out.item()) if sync else self._loss_out
 
 
 class GanTrainer:
