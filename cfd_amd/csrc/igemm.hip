@@ -399,6 +399,9 @@ static bool use_igemm256(const IgemmParams &p, int dtype) {
   if (mode >= 0) return mode != 0;
   // measured (scripts/layer_bench.py, B = 16..64): the ping-pong kernel wins once a slice runs >= 32 K tiles
   // and the launch fills at least half the chip; below that the 128x128 kernel's 2 blocks/CU hide more
+  // (f32 with at most half a 256-row m tile of real rows -- DeltaP fc1 at B = 128 -- is MFMA-bound on the empty half:
+  //  320 us on this kernel against 230 on the 128-row one)
+  if (dtype == CFD_F32 && p.M <= 128) return false;
   const int blocks = cdiv(p.M, 256) * (p.Cout / igemm256_ntile(p)) * p.nclass;
   const int s = split_k_256(p);
   // (an f32 K tile is 8x the MFMA time of a bf16 one, so a much shorter slice already amortises the prologue)
