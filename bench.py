@@ -39,6 +39,8 @@ WORKLOADS = {
     # (U/train.py:119-125): G predict, D on real, D on fake, composite GAN update -- incl. Adam and all-reduce
     "train_u_bf16": dict(nets=["U", "D"], dtype="bf16", batch=16, train=True),
     "train_u_fp32": dict(nets=["U", "D"], dtype="f32", batch=4, train=True),
+    # the DeltaP CNN's training step (DeltaP/train.py:131: one train_on_batch = forward, Huber loss, backward, Adam)
+    "train_deltap_bf16": dict(nets=["DeltaP"], dtype="bf16", batch=64, train=True),
 }
 
 
@@ -119,6 +121,18 @@ class TrainJob:
         out = self.gtr.train_on_batch(x, 1.0, y, seed=2 * step + 1, sample0=sample0,
                                       before_d=lambda: self.dtr.finish(sync=SYNC3))        # gan_model.train_on_batch
         return self.dloss.tolist() + out
+
+
+class CnnJob:
+    """DeltaP/train.py:131: model.train_on_batch(X, y) on the CNN regressor (Huber, Adam(1e-3, 0.5))"""
+
+    def __init__(self, tdt):
+        from cfd_amd import nets, trainer
+        self.c = nets.CnnRegressor(dtype=tdt, seed=5)
+        self.tr = trainer.CnnTrainer(self.c)
+
+    def step(self, x, y, step, sample0):
+        return self.tr.train_on_batch(x, y, seed=step, sample0=sample0)
 
 
 def run_step(models, x, step, sample0):
@@ -263,10 +277,13 @@ def run_model_workload(name, B, steps, warmup, rank, world, cpu_base):
     xs, us, _ = synthetic.model_batch([rank * B + i for i in range(B)])
     x = torch.from_numpy(xs).cuda()
     train = wl.get("train", False)
-    if train:
+    if train and wl["nets"] == ["DeltaP"]:
+        job = CnnJob(tdt)
+        y = torch.from_numpy(np.asarray([[0.1 + 0.01 * (i % 7)] for i in range(B)], dtype=np.float32)).cuda()   # DeltaP targets
+    elif train:
         job = TrainJob(tdt)
         y = torch.from_numpy(us).cuda()
-
+    if train:
         def step_fn(step):
             job.step(x, y, step, rank * B)
     else:
@@ -405,7 +422,8 @@ def main():
         k, w = max(3, min(args.steps, 10)), min(args.warmup, 2)
         for key, wname, B, base in (("infer_all_bf16", "infer_all_bf16", 0, False),
                                     ("train_u_bf16", "train_u_bf16", 16, cpu_base),
-                                    ("train_u_bf16_b32", "train_u_bf16", 32, False)):
+                                    ("train_u_bf16_b32", "train_u_bf16", 32, False),
+                                    ("train_deltap_bf16", "train_deltap_bf16", 0, False)):
             free_device_memory()
             also[key] = run_model_workload(wname, B, k, w, rank, world, base)
         free_device_memory()

@@ -656,32 +656,39 @@ __global__ __launch_bounds__(256) void tap_dw_kernel(const float *__restrict__ d
 // direct first-layer weight gradient: dw[co][tap][ci] += sum_pix dpre[pix][co] * patch(pix)[tap][ci], db[co] += sum dpre
 // (e1, c1, g1: Cin <= 2).  thread = output channel co, block = chunk of output pixels; the block's partial
 // sums are transposed through LDS so that the atomics of a wave hit contiguous addresses.
-template <typename T, int KS, int S, int CIN>
+template <typename T, int KS, int S, int CIN, int CGRP>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ x2,
                                                               int cin1, const T *__restrict__ dpre, int ldd,
                                                               float *__restrict__ dw, float *__restrict__ db, int B,
                                                               int Hi, int Wi, int Ho, int Wo, int Cout, int pix_per_block) {
+  // thread = (channel co, pixel group grp): CGRP = 64 / 128 / 256 threads cover the channels, the 256 / CGRP groups split
+  // the pixels of a step (with one thread per channel and nothing else, a 64-channel layer -- DeltaP g1 -- kept one wave of
+  // four busy).  Pixel indices are 32-bit (host: B * Ho * Wo < 2^31): the staging loop's three 64-bit divisions per element
+  // cost more than the step's FMAs.
   constexpr int NW = KS * KS * CIN;
-  constexpr int PIXB = 32;   // pixels per staged step: 32 independent dpre loads per thread in flight per barrier pair
+  constexpr int PIXB = 32;   // pixels per staged step
+  constexpr int G = 256 / CGRP, PPT = PIXB / G;   // pixel groups, pixels per thread and step
   __shared__ float patch[PIXB][NW];
-  __shared__ float outb[256 * (NW + 1)];   // [co][NW] padded by one against bank conflicts
-  const int64_t npix = (int64_t)B * Ho * Wo;
-  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
-  const int64_t p1 = (p0 + pix_per_block < npix) ? p0 + pix_per_block : npix;
-  const int co = threadIdx.x;
+  __shared__ float outb[256 * (NW + 1)];   // [thread][NW] padded by one against bank conflicts
+  __shared__ float outbias[256];
+  const unsigned npix = (unsigned)B * Ho * Wo;
+  const unsigned p0 = blockIdx.x * (unsigned)pix_per_block;
+  const unsigned p1 = (p0 + pix_per_block < npix) ? p0 + pix_per_block : npix;
+  const int co = threadIdx.x % CGRP, grp = threadIdx.x / CGRP;
   float acc[NW];
   float accb = 0.f;
 #pragma unroll
   for (int k = 0; k < NW; ++k) acc[k] = 0.f;
-  for (int64_t pb = p0; pb < p1; pb += PIXB) {
+  for (unsigned pb = p0; pb < p1; pb += PIXB) {
     __syncthreads();
     for (int e = threadIdx.x; e < PIXB * NW; e += 256) {
       const int pi = e / NW, k = e % NW;
-      const int64_t pix = pb + pi;
+      const unsigned pix = pb + pi;
       float v = 0.f;
       if (pix < p1) {
         const int ci = k % CIN, kw = (k / CIN) % KS, kh = k / (CIN * KS);
-        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((int64_t)Wo * Ho));
+        const unsigned row = pix / (unsigned)Wo;
+        const int ox = (int)(pix - row * Wo), b = (int)(row / (unsigned)Ho), oy = (int)(row - (unsigned)b * Ho);
         const int iy = oy * S - 1 + kh, ix = ox * S - 1 + kw;
         if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) {
           const size_t ip = ((size_t)b * Hi + iy) * Wi + ix;
@@ -692,29 +699,38 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
     }
     __syncthreads();
     if (co < Cout) {
-      float gv[PIXB];
+      float gv[PPT];
 #pragma unroll
-      for (int pi = 0; pi < PIXB; ++pi) {   // all loads first (clamped row, masked value): one latency per step
-        const int64_t pix = pb + pi;
-        const float g = to_f32(dpre[(pix < p1 ? pix : p1 - 1) * ldd + co]);
-        gv[pi] = pix < p1 ? g : 0.f;
+      for (int i = 0; i < PPT; ++i) {   // all loads first (clamped row, masked value): one latency per step
+        const unsigned pix = pb + grp + G * i;
+        const float g = to_f32(dpre[(size_t)(pix < p1 ? pix : p1 - 1) * ldd + co]);
+        gv[i] = pix < p1 ? g : 0.f;
       }
 #pragma unroll
-      for (int pi = 0; pi < PIXB; ++pi) {
-        accb += gv[pi];
+      for (int i = 0; i < PPT; ++i) {
+        accb += gv[i];
 #pragma unroll
-        for (int k = 0; k < NW; ++k) acc[k] = fmaf(gv[pi], patch[pi][k], acc[k]);
+        for (int k = 0; k < NW; ++k) acc[k] = fmaf(gv[i], patch[grp + G * i][k], acc[k]);
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < NW; ++k) outb[co * (NW + 1) + k] = acc[k];
+  for (int k = 0; k < NW; ++k) outb[threadIdx.x * (NW + 1) + k] = acc[k];
+  outbias[threadIdx.x] = accb;
   __syncthreads();
   for (int e = threadIdx.x; e < Cout * NW; e += 256) {
     const int c = e / NW, k = e - c * NW;
-    atomicAdd(dw + e, outb[c * (NW + 1) + k]);
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) t += outb[(g * CGRP + c) * (NW + 1) + k];
+    atomicAdd(dw + e, t);
   }
-  if (co < Cout && db) atomicAdd(db + co, accb);
+  if (threadIdx.x < Cout && db) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) t += outbias[g * CGRP + threadIdx.x];
+    atomicAdd(db + threadIdx.x, t);
+  }
 }
 
 // Streaming kernels get ONE vector per thread (no cap): measured on the Adam update over 128 Mi parameters
@@ -1003,6 +1019,7 @@ extern "C" int cfd_conv_first_wgrad(const float *x, const float *x2, int cin1, i
   hipStream_t st = (hipStream_t)stream;
   const int Ho = Hi / stride, Wo = Wi / stride;
   const int64_t npix = (int64_t)B * Ho * Wo;
+  CFD_REQUIRE(npix > 0 && npix < (1LL << 31) - 4096, "conv_first_wgrad: too many pixels");
   // ~1024 blocks of 32-pixel steps (32 dpre loads in flight per thread and barrier pair); each block ends with one
   // contiguous 4-32 KB atomic burst
   int64_t ppb = (npix + 1023) / 1024;
@@ -1010,13 +1027,19 @@ extern "C" int cfd_conv_first_wgrad(const float *x, const float *x2, int cin1, i
   ppb = (ppb + 31) / 32 * 32;
   const int blocks = (int)((npix + ppb - 1) / ppb);
   const int cin = cin1 + cin2;
-#define CFW(T, KS, S, CIN)                                                                                         \
-  hipLaunchKernelGGL((conv_first_wgrad_kernel<T, KS, S, CIN>), dim3(blocks), dim3(256), 0, st, x, x2, cin1,        \
+#define CFW_(T, KS, S, CIN, CG)                                                                                   \
+  hipLaunchKernelGGL((conv_first_wgrad_kernel<T, KS, S, CIN, CG>), dim3(blocks), dim3(256), 0, st, x, x2, cin1,    \
                      (const T *)dpre, ldd, dw, db, B, Hi, Wi, Ho, Wo, Cout, (int)ppb)
+#define CFW(T, KS, S, CIN)                                                                                         \
+  do {                                                                                                             \
+    if (Cout <= 64) CFW_(T, KS, S, CIN, 64); else if (Cout <= 128) CFW_(T, KS, S, CIN, 128);                      \
+    else CFW_(T, KS, S, CIN, 256);                                                                                 \
+  } while (0)
   if (ksize == 4 && stride == 2 && cin == 1) { if (dtype == CFD_BF16) CFW(bf16, 4, 2, 1); else CFW(float, 4, 2, 1); }
   else if (ksize == 4 && stride == 2 && cin == 2) { if (dtype == CFD_BF16) CFW(bf16, 4, 2, 2); else CFW(float, 4, 2, 2); }
   else if (ksize == 3 && stride == 1 && cin == 1) { if (dtype == CFD_BF16) CFW(bf16, 3, 1, 1); else CFW(float, 3, 1, 1); }
   else CFD_FAIL(CFD_EUNSUPPORTED, "conv_first_wgrad: k=%d s=%d cin=%d not built", ksize, stride, cin);
+#undef CFW_
 #undef CFW
   CFD_LAUNCH_CHECK();
   return CFD_OK;

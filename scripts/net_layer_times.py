@@ -29,7 +29,11 @@ def main():
     tdt = torch.float32 if wl["dtype"] == "f32" else torch.bfloat16
     xs, us, _ = synthetic.model_batch(list(range(B)))
     x = torch.from_numpy(xs).cuda()
-    if wl.get("train"):
+    if wl.get("train") and wl["nets"] == ["DeltaP"]:
+        job = bench.CnnJob(tdt)
+        y = torch.full((B, 1), 0.1, device="cuda")
+        step = lambda s: job.step(x, y, s, 0)
+    elif wl.get("train"):
         job = bench.TrainJob(tdt)
         y = torch.from_numpy(us).cuda()
         step = lambda s: job.step(x, y, s, 0)

@@ -302,11 +302,12 @@ def test_tap_family_backward(geom, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("k,s,c1,c2,cout", [(4, 2, 1, 0, 256), (4, 2, 1, 1, 128), (3, 1, 1, 0, 64)])
-def test_conv_first_wgrad(k, s, c1, c2, cout, dtype):
+@pytest.mark.parametrize("B,H,W", [(2, 16, 48), (3, 6, 22)])        # the second: a pixel count that is no multiple of a step
+@pytest.mark.parametrize("k,s,c1,c2,cout", [(4, 2, 1, 0, 256), (4, 2, 1, 1, 128), (3, 1, 1, 0, 64), (3, 1, 1, 0, 96),
+                                            (4, 2, 1, 0, 40)])     # 96 / 40: channels that do not fill their thread group
+def test_conv_first_wgrad(k, s, c1, c2, cout, B, H, W, dtype):
     from cfd_amd import ops
     dev = "cuda"
-    B, H, W = 2, 16, 48
     x = rnd((B, H, W, c1), 1)
     x2 = rnd((B, H, W, c2), 4) if c2 else None
     wk = rnd((k, k, c1 + c2, cout), 2, 0.1).requires_grad_(True)
