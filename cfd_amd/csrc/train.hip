@@ -666,8 +666,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
   // four busy).  Pixel indices are 32-bit (host: B * Ho * Wo < 2^31): the staging loop's three 64-bit divisions per element
   // cost more than the step's FMAs.
   constexpr int NW = KS * KS * CIN;
-  constexpr int PIXB = 32;   // pixels per staged step
-  constexpr int G = 256 / CGRP, PPT = PIXB / G;   // pixel groups, pixels per thread and step
+  constexpr int G = 256 / CGRP, PPT = 32;   // pixel groups; pixels per thread and step = dpre loads in flight per thread
+  constexpr int PIXB = PPT * G;             // pixels per staged step
   __shared__ float patch[PIXB][NW];
   __shared__ float outb[256 * (NW + 1)];   // [thread][NW] padded by one against bank conflicts
   __shared__ float outbias[256];
@@ -679,7 +679,16 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
   float accb = 0.f;
 #pragma unroll
   for (int k = 0; k < NW; ++k) acc[k] = 0.f;
+  const int cc = co < Cout ? co : Cout - 1;          // (threads beyond Cout load a valid address and contribute nothing)
   for (unsigned pb = p0; pb < p1; pb += PIXB) {
+    // the step's gradient rows first: their latency runs under the patch staging (both were serial: 2 round trips per step)
+    float gv[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const unsigned pix = pb + grp + G * i;
+      const float g = to_f32(dpre[(size_t)(pix < p1 ? pix : p1 - 1) * ldd + cc]);
+      gv[i] = pix < p1 ? g : 0.f;
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < PIXB * NW; e += 256) {
       const int pi = e / NW, k = e % NW;
@@ -699,13 +708,6 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
     }
     __syncthreads();
     if (co < Cout) {
-      float gv[PPT];
-#pragma unroll
-      for (int i = 0; i < PPT; ++i) {   // all loads first (clamped row, masked value): one latency per step
-        const unsigned pix = pb + grp + G * i;
-        const float g = to_f32(dpre[(size_t)(pix < p1 ? pix : p1 - 1) * ldd + co]);
-        gv[i] = pix < p1 ? g : 0.f;
-      }
 #pragma unroll
       for (int i = 0; i < PPT; ++i) {
         accb += gv[i];
@@ -1024,7 +1026,7 @@ extern "C" int cfd_conv_first_wgrad(const float *x, const float *x2, int cin1, i
   // contiguous 4-32 KB atomic burst
   int64_t ppb = (npix + 1023) / 1024;
   if (ppb < 64) ppb = 64;
-  ppb = (ppb + 31) / 32 * 32;
+  ppb = (ppb + 127) / 128 * 128;     // a multiple of every variant's step (32 pixels x 1, 2 or 4 groups)
   const int blocks = (int)((npix + ppb - 1) / ppb);
   const int cin = cin1 + cin2;
 #define CFW_(T, KS, S, CIN, CG)                                                                                   \
