@@ -46,9 +46,10 @@ __device__ __forceinline__ bf16x8 tr_read2(const char *lds, unsigned o0, unsigne
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// PAIR (conv kinds with Cin == 128 and an even kernel width, e.g. the discriminator's c2): the 256 ci columns of a tile are
-// TWO horizontally adjacent taps x 128 channels -- B0 = tap t, B1 = tap t + 1 (the same 128 channels one input pixel to the
-// right, with its own in-image test); dW's [tap][ci] columns are contiguous, so the epilogue is unchanged.
+// PAIR (conv kinds with Cin == 128: the discriminator's c2, DeltaP g4): the 256 ci columns of a tile are TWO consecutive
+// taps x 128 channels -- B0 = tap t, B1 = tap t + 1 (the same 128 channels at that tap's own pixel offset, with its own
+// in-image test); dW's [tap][ci] columns are contiguous, so the epilogue is unchanged except that an odd tap count (3x3)
+// leaves the last pair without a second tap: its B1 loads nothing and its columns are not stored.
 template <bool GATHER_A, bool PAIR>
 __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -70,6 +71,9 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
   const int co0 = cot * 256, ci0 = cit * 256;
   const int kh = tap / p.ktaps_w, kw = tap - kh * p.ktaps_w;
   const int oy = kh + p.oy_base, ox = kw + p.ox_base;
+  const bool has2 = PAIR && tap + 1 < p.ntaps;
+  const int kh2 = (tap + 1) / p.ktaps_w, kw2 = (tap + 1) - kh2 * p.ktaps_w;
+  const int oy2 = kh2 + p.oy_base, ox2 = kw2 + p.ox_base;
 
   const int ktiles = (p.M + 63) >> 6;
   const int kbeg = k_slice(ktiles, sm, p.split_m);       // 32-bit: ktiles * split_m < 2^31 (host)
@@ -83,8 +87,8 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
   // 8 + w: rows R_i = (i*8 + w)*4 + lane/16, physical 16-B slot lane%16 holding LOGICAL chunk slot ^ (R & 15)
   const int lrow = lane >> 4, slot = lane & 15;
   const int cplain = GATHER_A ? ci0 : co0, cgath = GATHER_A ? co0 : ci0;
-  unsigned pv[2], gl[2], cur[2], cur1[2];
-  int gyl[2], gxl[2];
+  unsigned pv[2], gl[2], gl2[2], cur[2], cur1[2];
+  int gyl[2], gxl[2], gyl2[2], gxl2[2];
   const int Wm_mask = (1 << p.lw) - 1, Hm_mask = (1 << p.lh) - 1;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -95,6 +99,9 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
     gyl[i] = qyl * p.S + oy;
     gxl[i] = qxl * p.S + ox;
     gl[i] = (unsigned)((((bl * p.Hg + gyl[i]) * p.Wg + gxl[i]) * p.ldg + cgath + lchunk * 8) * 2 + (int)p.margin);
+    gyl2[i] = qyl * p.S + oy2;
+    gxl2[i] = qxl * p.S + ox2;
+    gl2[i] = (unsigned)((((bl * p.Hg + gyl2[i]) * p.Wg + gxl2[i]) * p.ldg + cgath + lchunk * 8) * 2 + (int)p.margin);
   }
 
   // ---- issue stream state (uniform)
@@ -108,9 +115,9 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
     s_g = (unsigned)(((bs * p.Hg + gys) * p.Wg + gxs) * p.ldg * 2);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const bool oky = (unsigned)(gyl[i] + gys) < (unsigned)p.Hg;
-      cur[i] = oky && (unsigned)(gxl[i] + gxs) < (unsigned)p.Wg ? gl[i] : WOOB;
-      if (PAIR) cur1[i] = oky && (unsigned)(gxl[i] + gxs + 1) < (unsigned)p.Wg ? gl[i] + (unsigned)(p.ldg * 2) : WOOB;
+      cur[i] = (unsigned)(gyl[i] + gys) < (unsigned)p.Hg && (unsigned)(gxl[i] + gxs) < (unsigned)p.Wg ? gl[i] : WOOB;
+      if (PAIR)
+        cur1[i] = has2 && (unsigned)(gyl2[i] + gys) < (unsigned)p.Hg && (unsigned)(gxl2[i] + gxs) < (unsigned)p.Wg ? gl2[i] : WOOB;
     }
   };
   auto iss_advance = [&]() {
@@ -239,6 +246,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(Wgrad256Params p) {
       const int rowoff = base + ((i >> 2) * 128 + (i & 3) * 16 + r) * row_stride;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (PAIR && (j >> 1) && !has2) continue;      // (uniform) the odd last tap has no partner: those columns do not exist
         float *q = dst + rowoff + (j >> 1) * 128 + (j & 1) * 16;
         if (atomics) atomicAdd(q, acc[i][j][r]);
         else *q = acc[i][j][r];
@@ -263,7 +271,7 @@ static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // fills `p` (without pointers) and returns true when the 256x256 kernel can run this layer
 bool wgrad256_plan(const cfd_conv_desc *d, Wgrad256Params &p) {
   memset(&p, 0, sizeof(p));
-  const bool pair = d->Cin == 128 && (d->kind == CFD_CONV_K4S2 || d->kind == CFD_CONV_K4S1);
+  const bool pair = d->Cin == 128 && (d->kind == CFD_CONV_K4S2 || d->kind == CFD_CONV_K4S1 || d->kind == CFD_CONV_K3S1);
   if (d->dtype != CFD_BF16 || (d->Cin % 256 && !pair) || d->Cout % 256) return false;
   int Hy, Wy, Hm, Wm;
   switch (d->kind) {
@@ -298,7 +306,7 @@ bool wgrad256_plan(const cfd_conv_desc *d, Wgrad256Params &p) {
   p.pbytes = (unsigned)pb; p.gbytes = (unsigned)(gb + margin); p.margin = (unsigned)margin;
   p.pair = pair;
   p.cotiles = d->Cout / 256; p.citiles = pair ? 1 : d->Cin / 256;
-  p.tap_groups = pair ? p.ntaps / 2 : p.ntaps;
+  p.tap_groups = pair ? (p.ntaps + 1) / 2 : p.ntaps;
   return true;
 }
 

@@ -104,6 +104,8 @@ WG256 = [
     ("k4s2", 2, 16, 32, 128, 256, 1),    # Cin = 128: a tile's ci columns are two adjacent taps (the discriminator's c2)
     ("k4s2", 3, 8, 128, 128, 512, 3),    # the same with a ragged split and one grid row per K tile
     ("k4s1", 2, 4, 32, 128, 256, 2),     # stride 1, asymmetric padding: the second tap of a pair leaves the image on the right
+    ("k3s1", 2, 8, 16, 128, 256, 1),     # nine taps: pairs cross kernel rows, the ninth tap has no partner (DeltaP g4)
+    ("k3s1", 3, 4, 32, 128, 512, 2),
 ]
 
 
