@@ -315,6 +315,13 @@ int wgrad256_suggest_split(const Wgrad256Params &p) {
   const int ktiles = (p.M + 63) / 64;
   int s = 1;
   while (tiles * s * 2 <= 512 && ktiles / (s * 2) >= 16) s *= 2;
+  // tile counts that are no power of two (nine taps, five tap pairs): doubling lands on 288 or 320 blocks, i.e. a
+  // second round on a quarter of the CUs; take the largest factor that still fits two full rounds instead
+  if ((tiles & (tiles - 1)) != 0 && tiles < 512) {
+    int t = 512 / tiles;
+    if (t > ktiles / 16) t = ktiles / 16;
+    if (t > s) s = t;
+  }
   return s;
 }
 
