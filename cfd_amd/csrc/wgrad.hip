@@ -26,6 +26,7 @@ struct WgradParams {
   int B, Hx, Wx, Hy, Wy, Cin, Cout, ldx, ldy;
   int Hm, Wm, M;   // reduction grid
   int kind, ntaps, flip;
+  int pair, tap_groups;   // pair: bf16 conv kinds with Cin == 64 -- a 128-channel tile row holds taps t and t + 1 (64 channels each)
   int cotiles, citiles, split_m;
   unsigned long long magicW, magicHW;  // exact division of m by Wm and by Hm*Wm: q = (m * magic) >> (32 + shift)
   int shiftW, shiftHW;
@@ -60,8 +61,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   int bid = blockIdx.x;
   const int cit = bid % p.citiles; bid /= p.citiles;
   const int cot = bid % p.cotiles; bid /= p.cotiles;
-  const int tap = bid % p.ntaps;
-  const int sm = bid / p.ntaps;
+  const int tap = (bid % p.tap_groups) * (p.pair ? 2 : 1);
+  const int sm = bid / p.tap_groups;
   const int co0 = cot * CT, ci0 = cit * CT;
 
   // tap geometry: offsets applied to the gathered operand
@@ -73,6 +74,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   const int S = (p.kind == CFD_CONV_K4S2 || transposed) ? 2 : 1;
   const int pad = (p.kind == CFD_DENSE) ? 0 : 1;
   const int oy = kh - pad, ox = kw - pad;  // gathered pixel = grid pixel * S + (oy, ox)
+  // pair mode: the second tap of the tile (columns 64..127); an odd tap count leaves the last pair without one
+  const bool has2 = p.pair && tap + 1 < p.ntaps;
+  int kh2, kw2;
+  if (p.kind == CFD_CONV_K3S1) { kh2 = (tap + 1) / 3; kw2 = (tap + 1) - kh2 * 3; }
+  else { kh2 = (tap + 1) >> 2; kw2 = (tap + 1) & 3; }
+  const int oy2 = kh2 - pad, ox2 = kw2 - pad;
 
   // staging: one wave-instruction = 1 KiB = 4 rows x 256 B; lane -> row lane/16, chunk slot lane%16.
   // round r (0..3) of wave w covers tile rows (r*4 + w)*4 + lane/16
@@ -97,11 +104,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
         const int qy = fastdiv(rem, p.magicW, p.shiftW);
         const int qx = rem - qy * p.Wm;
         // plain operand pixel == m; gathered operand pixel = (qy*S+oy, qx*S+ox) on its own grid
-        const int gy = qy * S + oy, gx = qx * S + ox;
-        const int cop = co0 + lchunk * EPC, cip = ci0 + lchunk * EPC;
+        const bool second = p.pair && lchunk * EPC >= 64;
+        const int gy = qy * S + (second ? oy2 : oy), gx = qx * S + (second ? ox2 : ox);
+        const int cop = co0 + lchunk * EPC, cip = p.pair ? (lchunk * EPC) & 63 : ci0 + lchunk * EPC;
         if (!transposed) {
           if (cop < p.Cout) ps = p.dy + ((int64_t)m * p.ldy + cop) * ES;
-          if (cip < p.Cin && (unsigned)gy < (unsigned)p.Hx && (unsigned)gx < (unsigned)p.Wx)
+          if (cip < p.Cin && (!second || has2) && (unsigned)gy < (unsigned)p.Hx && (unsigned)gx < (unsigned)p.Wx)
             qs = p.x + ((int64_t)((b * p.Hx + gy) * p.Wx + gx) * p.ldx + cip) * ES;
         } else {
           if (cip < p.Cin) qs = p.x + ((int64_t)m * p.ldx + cip) * ES;
@@ -183,13 +191,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   }
 
   // ---- store / accumulate: lane holds dW[co = .. + fq*4 + r][ci = .. + fr]
-  const int wtap = p.flip ? (p.ntaps - 1 - tap) : tap;
 #pragma unroll
   for (int i = 0; i < FR; ++i)
 #pragma unroll
     for (int j = 0; j < FR; ++j) {
-      const int ci = ci0 + wci + j * 16 + fr;
-      if (ci >= p.Cin) continue;
+      int ci = ci0 + wci + j * 16 + fr;
+      int tapx = tap;
+      if (p.pair) {
+        if (ci >= 64) { if (!has2) continue; tapx = tap + 1; ci -= 64; }
+      } else if (ci >= p.Cin) continue;
+      const int wtap = p.flip ? (p.ntaps - 1 - tapx) : tapx;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wco + i * 16 + fq * 4 + r;
@@ -249,11 +260,14 @@ static int conv_wgrad_impl(const cfd_conv_desc *d, const void *x, const void *dy
   const int ct = d->dtype == CFD_BF16 ? 128 : 64;
   p.cotiles = cdiv(d->Cout, ct);
   p.citiles = cdiv(d->Cin, ct);
+  p.pair = d->dtype == CFD_BF16 && d->Cin == 64 &&
+           (d->kind == CFD_CONV_K4S2 || d->kind == CFD_CONV_K4S1 || d->kind == CFD_CONV_K3S1);
+  p.tap_groups = p.pair ? (p.ntaps + 1) / 2 : p.ntaps;
   const int mchunks = (p.M + 63) / 64;
   p.split_m = split_m < mchunks ? split_m : mchunks;
   make_magic(p.Wm, p.magicW, p.shiftW);
   make_magic(p.Hm * p.Wm, p.magicHW, p.shiftHW);
-  const int64_t nb = (int64_t)p.cotiles * p.citiles * p.ntaps * p.split_m;
+  const int64_t nb = (int64_t)p.cotiles * p.citiles * p.tap_groups * p.split_m;
   CFD_REQUIRE(nb < (1LL << 31), "grid too large");
   p.nblocks = (int)nb;
   hipStream_t st = (hipStream_t)stream;
@@ -307,7 +321,9 @@ extern "C" int cfd_conv_wgrad_suggest_split(const cfd_conv_desc *d) {
     default: ntaps = 16; Hm = d->Hi; Wm = d->Wi; break;
   }
   const int ct = d->dtype == CFD_BF16 ? 128 : 64;
-  const int64_t tiles = (int64_t)cdiv(d->Cout, ct) * cdiv(d->Cin, ct) * ntaps;
+  const bool pair = d->dtype == CFD_BF16 && d->Cin == 64 &&
+                    (d->kind == CFD_CONV_K4S2 || d->kind == CFD_CONV_K4S1 || d->kind == CFD_CONV_K3S1);
+  const int64_t tiles = (int64_t)cdiv(d->Cout, ct) * cdiv(d->Cin, ct) * (pair ? (ntaps + 1) / 2 : ntaps);
   const int64_t mchunks = ((int64_t)d->B * Hm * Wm + 63) / 64;
   int s = 1;
   while (tiles * s * 2 <= 1024 && mchunks / (s * 2) >= 8) s *= 2;

@@ -29,7 +29,7 @@ def q(t, dtype):
 CONVS = [
     ("k4s2", 2, 8, 16, 64, 128), ("k4s2", 3, 4, 12, 128, 64), ("k4s1", 2, 4, 32, 128, 128),
     ("k3s1", 2, 8, 16, 64, 128), ("convT", 2, 4, 8, 128, 128), ("convT", 1, 1, 8, 64, 256),
-    ("dense", 5, 1, 1, 512, 256), ("dense", 3, 1, 1, 128, 8),
+    ("dense", 5, 1, 1, 512, 256), ("dense", 3, 1, 1, 128, 8), ("k4s1", 2, 4, 32, 64, 192), ("k3s1", 1, 6, 10, 64, 64),
 ]
 
 
