@@ -39,6 +39,7 @@ WORKLOADS = {
     # (U/train.py:119-125): G predict, D on real, D on fake, composite GAN update -- incl. Adam and all-reduce
     "train_u_bf16": dict(nets=["U", "D"], dtype="bf16", batch=16, train=True),
     "train_u_fp32": dict(nets=["U", "D"], dtype="f32", batch=4, train=True),
+    "train_p_bf16": dict(nets=["P", "D"], dtype="bf16", batch=16, train=True),      # P/train.py: the same step on the P generator
     # the DeltaP CNN's training step (DeltaP/train.py:131: one train_on_batch = forward, Huber loss, backward, Adam)
     "train_deltap_bf16": dict(nets=["DeltaP"], dtype="bf16", batch=64, train=True),
 }
@@ -101,9 +102,9 @@ SYNC3 = os.environ.get("CFD_BENCH_SYNC3", "0") == "1"     # A/B: read every loss
 
 
 class TrainJob:
-    def __init__(self, tdt):
+    def __init__(self, tdt, arch="U"):
         from cfd_amd import nets, trainer
-        self.g = nets.Generator("U", dtype=tdt, seed=7)
+        self.g = nets.Generator(arch, dtype=tdt, seed=7)
         self.d = nets.Discriminator(dtype=tdt, seed=8)
         self.dtr = trainer.DiscriminatorTrainer(self.d)
         self.gtr = trainer.GanTrainer(self.g, self.d)
@@ -281,7 +282,7 @@ def run_model_workload(name, B, steps, warmup, rank, world, cpu_base):
         job = CnnJob(tdt)
         y = torch.from_numpy(np.asarray([[0.1 + 0.01 * (i % 7)] for i in range(B)], dtype=np.float32)).cuda()   # DeltaP targets
     elif train:
-        job = TrainJob(tdt)
+        job = TrainJob(tdt, wl["nets"][0])
         y = torch.from_numpy(us).cuda()
     if train:
         def step_fn(step):
