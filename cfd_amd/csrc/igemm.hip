@@ -408,7 +408,10 @@ static bool use_igemm256(const IgemmParams &p, int dtype) {
   // (B = 128: with >= 4 tiles queued per CU a 16-K-tile bf16 layer -- DeltaP g4, K = 9 x 128 -- runs 0.97 PFLOP/s
   //  here against 0.70 on the 128x128 kernel)
   const int kt = (p.ntaps * p.cpt) / s;
-  return blocks * s >= 128 && (kt >= (dtype == CFD_BF16 ? 32 : 8) || (blocks >= 1024 && kt >= 16));
+  // (the 128(n) x 256(m) variant with >= 4 tiles queued per CU already wins at 9 K tiles: DeltaP g3, K = 9 x 64, 272 us
+  //  against 311 on the 128x128 kernel at B = 128)
+  const int kt_many = igemm256_ntile(p) == 128 ? 8 : 16;
+  return blocks * s >= 128 && (kt >= (dtype == CFD_BF16 ? 32 : 8) || (blocks >= 1024 && kt >= kt_many));
 }
 
 extern "C" int cfd_conv_suggest_split_k(const cfd_conv_desc *d) {
