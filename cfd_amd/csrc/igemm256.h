@@ -1,0 +1,50 @@
+// Shared between the 256-wide ping-pong kernels (igemm256.hip: one LDS tile per tap; igemm256h.hip: the activation
+// operand staged once per channel chunk as an input patch).
+#pragma once
+#include "common.h"
+#include "igemm.h"
+
+namespace cfd {
+
+constexpr int HT_BYTES = 128 * 128;   // half tile
+constexpr int ST_BYTES = 4 * HT_BYTES;
+constexpr unsigned OOB = 0x80000000u;  // voffset beyond any num_records we accept (< 2^31): reads as zero
+
+struct Igemm256Params {
+  IgemmParams g;
+  unsigned xbytes, wbytes;   // buffer sizes for the range check
+  int tapinfo[4][16];        // per class, per tap: (dy*Wi + dx) pixel offset << 8 | weight tap index
+  short tapdy[4][16], tapdx[4][16];
+  int cls_fast;              // block order: 1 = the sub-pixel classes of one pixel tile are adjacent blocks
+  int tgeo[4][8];            // per class: kw, kh, dy0, dys, dx0, dxs -- the taps form a kh x kw grid, tap t = ky*kw + kx
+                             // sits at (dy0 + dys*ky, dx0 + dxs*kx)
+  int stage_out;             // bf16 output tile goes through LDS and leaves as whole 512-B pixel rows
+};
+
+// LDS-staged output (bf16, no split-K): measured with the stamp build, the direct epilogue -- 32 stores per lane, each
+// wave instruction scattering 16 segments of 32 B -- took 7.6 K tiles' worth per tile (~11 us); staged, a wave
+// instruction stores two whole 512-B pixel rows.
+constexpr int OUT_ROW = 528;               // 512 B of channels + 16 B pad (bank spread of the fragment writes)
+constexpr int OUT_OFF = 8192;              // after the statistics partials
+constexpr int OUT_LDS = OUT_OFF + 256 * OUT_ROW;
+
+__device__ __forceinline__ void bload16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char *lds_dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_dst, 16, (int)voff,
+                                           (int)soff, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
+  return c;
+}
+
+// igemm256h.hip: patch-staged variant (bf16, 3x3 stride 1 and the transposed 4x4 stride 2, no split-K).  `p` as prepared
+// by igemm256_launch (mtiles / ntiles / nblocks for 256 x 256 tiles).
+bool igemm256h_eligible(const IgemmParams &p, int dtype);
+int igemm256h_launch(const IgemmParams &p, unsigned xbytes, unsigned wbytes, int cls_fast, int stage_out, hipStream_t st);
+
+}  // namespace cfd

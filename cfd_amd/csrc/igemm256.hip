@@ -27,31 +27,10 @@
 //     so the counts stay uniform.
 #include "common.h"
 #include "igemm.h"
+#include "igemm256.h"
 #include <type_traits>
 
 namespace cfd {
-
-constexpr int HT_BYTES = 128 * 128;   // half tile
-constexpr int ST_BYTES = 4 * HT_BYTES;
-constexpr unsigned OOB = 0x80000000u;  // voffset beyond any num_records we accept (< 2^31): reads as zero
-
-struct Igemm256Params {
-  IgemmParams g;
-  unsigned xbytes, wbytes;   // buffer sizes for the range check
-  int tapinfo[4][16];        // per class, per tap: (dy*Wi + dx) pixel offset << 8 | weight tap index
-  short tapdy[4][16], tapdx[4][16];
-  int cls_fast;              // block order: 1 = the sub-pixel classes of one pixel tile are adjacent blocks
-  int tgeo[4][8];            // per class: kw, kh, dy0, dys, dx0, dxs -- the taps form a kh x kw grid, tap t = ky*kw + kx
-                             // sits at (dy0 + dys*ky, dx0 + dxs*kx)
-  int stage_out;             // bf16 output tile goes through LDS and leaves as whole 512-B pixel rows
-};
-
-// LDS-staged output (bf16, no split-K): measured with the stamp build, the direct epilogue -- 32 stores per lane, each
-// wave instruction scattering 16 segments of 32 B -- took 7.6 K tiles' worth per tile (~11 us); staged, a wave
-// instruction stores two whole 512-B pixel rows.
-constexpr int OUT_ROW = 528;               // 512 B of channels + 16 B pad (bank spread of the fragment writes)
-constexpr int OUT_OFF = 8192;              // after the statistics partials
-constexpr int OUT_LDS = OUT_OFF + 256 * OUT_ROW;
 
 // validity bits (bit t = tap t reads inside the image) of one class for the pixel whose stride-scaled origin is
 // (y0, x0): 8 compares on the affine tap grid instead of one table load per tap (the address set-up of a tile is
@@ -98,20 +77,6 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else static_assert(N < 0, "unsupported vmcnt");
-}
-
-__device__ __forceinline__ void bload16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char *lds_dst) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_dst, 16, (int)voff,
-                                           (int)soff, 0, 0);
-}
-
-__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
-  return c;
 }
 
 // T = bf16: K tile = 64 elements, mfma_f32_16x16x32_bf16.  T = float: K tile = 32 elements, exact-f32
@@ -1201,6 +1166,9 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   }
   const size_t shmem = (P.stage_out || p.pool) ? (size_t)OUT_LDS : (size_t)2 * ST_BYTES;
   const int pdt = tuning(CFD_TUNE_IGEMM256_PD);
+  // stride-1 tap grids on whole 8 x 32 pixel tiles: the activation operand is staged once per channel chunk (igemm256h.hip)
+  if (pdt < 0 && ntile == 256 && igemm256h_eligible(p, dtype))
+    return igemm256h_launch(p, P.xbytes, P.wbytes, P.cls_fast, P.stage_out, st);
   // persistent form (igemm256p_kernel): bf16, 256-wide n tiles, more tiles than CUs, every K range even
   // (CFD_TUNE_IGEMM256_PD: 36 forces it where legal, 26 forbids it)
   const int ktiles_all = p.ntaps * p.cpt;

@@ -1,0 +1,401 @@
+// bf16 implicit-GEMM convolution, 256(n) x 256(m) ping-pong tile, with the ACTIVATION operand staged once per 64-channel
+// chunk as an input patch instead of once per tap.
+//
+// Why (note (f)): the PMC counters show igemm256's L2 channels 90 % busy at ~11.8 TB/s of requests --
+// the kernel is bound by the bytes it fills into LDS (64 KiB per K tile: 32 KiB of weights + 32 KiB of gathered
+// activations), not by the MFMA pipe or HBM.  The gathered operand of a stride-1 tap grid is the same input pixels shifted
+// by the tap: a tile of 8 x 32 output pixels needs an (8 + kh - 1) x (32 + kw - 1) input patch, which is loaded ONCE per
+// chunk (43 KiB for 3x3, 39 KiB for one sub-pixel class of the transposed 4x4) and read by the MFMA side at tap-shifted
+// rows.  Fill per K tile falls from 64 KiB to 32 + 43/9 = 37 KiB (3x3) and 32 + 39/4 = 42 KiB (transposed).
+//
+// Differences from igemm256_kernel (igemm256.hip), whose structure (8 waves, two groups one barrier apart, two phases
+// of 32 MFMAs per K tile, LDS-DMA with counted vmcnt, XOR-swizzled 128-B rows) is kept:
+//   * m tile = 8 rows x 32 columns of ONE sample's class grid (host: Hq % 8 == 0, Wq % 32 == 0), m local = ty*32 + tx;
+//     wave (wr, wc) owns tile rows wc and 4 + wc (its four B fragments = 16-pixel runs of those rows).
+//   * K order is chunk-major: K tile k = chunk * NT + tap.  LDS = two stages of (A0, A1) weight half tiles (64 KiB) + two
+//     patch stages.  A patch row is one patch pixel (128 B = 64 channels), pixel pp = py * 34 + px, its 16-B chunks
+//     swizzled by pp & 7; the B fragment of tap (dy, dx) for tile pixel (ty, tx) is patch pixel (ty + dy - dymin) * 34 +
+//     (tx + dx - dxmin): ONE lane base address per tap, the four fragments at immediate offsets (the row pitch 34 keeps
+//     4 * 34 = 0 mod 8, so the swizzle key is the same for all four).
+//   * the patch of chunk c + 1 is loaded during the first K tiles of chunk c (1 or 2 extra loads per wave per K tile, none
+//     in the chunk's last K tile, so the wait that ends it -- vmcnt(4) -- retires the whole patch); padding = patch pixels
+//     outside the image get an out-of-range voffset, which the hardware zero-fills.
+//   * vmcnt bookkeeping: phase A of K tile k issues [patch loads n_t] + A1(k+1), phase B issues A0(k+2); both phases end
+//     with vmcnt(4 + n_t), which retires A1(k) / A0(k+1) respectively.
+//   * no split-K, no pooled epilogue (the host keeps those layers on igemm256_kernel).
+#include "common.h"
+#include "igemm.h"
+#include "igemm256.h"
+#include <type_traits>
+
+namespace cfd {
+
+constexpr int H_TH = 8, H_TW = 32, H_PW = 34;
+constexpr int H_ABYTES = 4 * HT_BYTES;   // two stages of (A0, A1)
+constexpr int H_BROW = 4 * H_PW * 128;   // byte distance between a wave's two tile rows (wc and 4 + wc) in the patch
+
+template <int NT> struct HaloGeo {
+  static constexpr int PH = H_TH + (NT == 9 ? 2 : 1);
+  static constexpr int PP = PH * H_PW;           // patch pixels
+  static constexpr int NPI = (PP + 7) / 8;       // wave-level load instructions (8 pixels = 1 KiB each)
+  static constexpr int PPW = (NPI + 7) / 8;      // ... per wave
+  static constexpr int PER = (PPW + NT - 2) / (NT - 1);   // per K tile, so that the chunk's last K tile carries none
+  static constexpr int PATCH = NPI * 1024;
+  static constexpr int LDS = H_ABYTES + 2 * PATCH;
+  static constexpr int first(int t) { return t * PER < PPW ? t * PER : PPW; }
+  static constexpr int count(int t) { return first(t + 1) - first(t); }
+  static_assert(first(NT - 1) == PPW, "the last K tile of a chunk must not carry patch loads");
+  static_assert(LDS <= 160 * 1024 && LDS >= OUT_LDS, "LDS budget");
+};
+
+struct IgemmHaloParams {
+  IgemmParams g;
+  unsigned xbytes, wbytes;
+  int cls_fast, stage_out;
+  int toff[4][9];      // per class, per tap: pixel offset of the tap inside the patch, (dy - dymin) * 34 + (dx - dxmin)
+  int wtoff[4][9];     // per class, per tap: byte offset of the tap's Cin weights inside a weight row
+  int dymin[4], dxmin[4];
+  int tps, tpr;        // m tiles per sample, per tile row
+};
+
+template <int N> __device__ __forceinline__ void hwait() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else static_assert(N < 0, "unsupported vmcnt");
+}
+
+template <int V> using IC = std::integral_constant<int, V>;
+
+template <int NT>
+__global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  using G = HaloGeo<NT>;
+  const IgemmParams &p = P.g;
+  typedef bf16x8 frag_t;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const float act_ns = act_neg_scale(p.act, p.slope);
+  const bool act_any = p.act == CFD_ACT_LEAKY || p.act == CFD_ACT_RELU;   // (uniform)
+  const bool act_sig = p.act == CFD_ACT_SIGMOID;
+
+  // ---- XCD-aware block remap (bijective), as in igemm256_kernel
+  int bid = blockIdx.x;
+  {
+    const int nwg = p.nblocks, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = bid % p.ntiles; bid /= p.ntiles;
+  int mt, cls;
+  if (P.cls_fast) { cls = bid % p.nclass; bid /= p.nclass; mt = bid; }
+  else { mt = bid % p.mtiles; bid /= p.mtiles; cls = bid; }
+  const int ph = cls >> 1, pw = cls & 1;
+  const int n0 = nt * 256;
+  const int b = mt / P.tps;
+  const int trem = mt - b * P.tps;
+  const int tyi = trem / P.tpr;
+  const int ty0 = tyi * H_TH, tx0 = (trem - tyi * P.tpr) * H_TW;
+  const int cpt = p.cpt;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)P.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)P.wbytes, 0x00020000);
+
+  int toff[NT], wto[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    toff[t] = __builtin_amdgcn_readfirstlane(P.toff[cls][t]);
+    wto[t] = __builtin_amdgcn_readfirstlane(P.wtoff[cls][t]);
+  }
+
+  // ---- staging geometry: a wave-level load = 1 KiB = 8 rows x 128 B; lane -> row lane/8, physical chunk lane%8, which
+  // holds the LOGICAL chunk (lane%8) ^ (row & 7) (swizzle on the source address; the LDS image stays lane-linear)
+  const int lrow = lane >> 3;
+  const int chunk = (lane & 7) ^ lrow;
+  unsigned avoff[4];   // weights: row (n0 + half*128 + piece*64 + wave*8 + lrow), r = half*2 + piece
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    avoff[r] = (unsigned)(((n0 + (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow) * p.Kw + chunk * 8) * 2);
+  unsigned pvoff[G::PPW];   // patch: load j of this wave covers patch pixels q*8 .. q*8+7, q = min(j*8 + wave, NPI-1)
+  {
+    const int py0 = ty0 + P.dymin[cls], px0 = tx0 + P.dxmin[cls];
+#pragma unroll
+    for (int j = 0; j < G::PPW; ++j) {
+      const int q = min(j * 8 + wave, G::NPI - 1);
+      const int pp = q * 8 + lrow;
+      const int py = pp / H_PW, px = pp - py * H_PW;
+      const int y = py0 + py, x = px0 + px;
+      const bool ok = pp < G::PP && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+      pvoff[j] = ok ? (unsigned)((((b * p.Hi + y) * p.Wi + x) * p.ldx + chunk * 8) * 2) : OOB;
+    }
+  }
+
+  char *const ldsw = lds + wave * 1024;
+  auto issueA0 = [&](int st, unsigned sa) {
+    char *dst = ldsw + st * (2 * HT_BYTES);
+    bload16(wrs, avoff[0], sa, dst); bload16(wrs, avoff[1], sa, dst + 8192);
+  };
+  auto issueA1 = [&](int st, unsigned sa) {
+    char *dst = ldsw + st * (2 * HT_BYTES) + HT_BYTES;
+    bload16(wrs, avoff[2], sa, dst); bload16(wrs, avoff[3], sa, dst + 8192);
+  };
+  auto issueP = [&](int j, int pst, unsigned sp) {   // j: compile-time at every call site
+    const int q = min(j * 8 + wave, G::NPI - 1);
+    bload16(xrs, pvoff[j], sp, lds + H_ABYTES + pst * G::PATCH + q * 1024);
+  };
+
+  // ---- fragment read offsets
+  const int fr = lane & 15, fq = lane >> 4;
+  const int laneoff = fr * 128 + ((fq ^ (fr & 7)) << 4);
+  const char *ard[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) ard[s] = lds + ((wr * 64 * 128 + laneoff) ^ (s << 6));
+  const int L0 = wc * H_PW + fr;   // patch pixel of (tile row wc, column fr) for a tap at the patch origin
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: patch of chunk 0, A0(0), A1(0), A0(1)
+#pragma unroll
+  for (int j = 0; j < G::PPW; ++j) issueP(j, 0, 0u);
+  issueA0(0, (unsigned)wto[0]);
+  issueA1(0, (unsigned)wto[0]);
+  issueA0(1, (unsigned)(wto[1 % NT] + min(1 / NT, cpt - 1) * 128));
+  hwait<4>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // second group runs one barrier behind
+
+  frag_t a[4][2], b0[2][2], b1[2][2];
+
+#define CFD_MFMA(AI, BJ, BREG)                                                         \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s)                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                \
+            acc[AI + i][BJ + j] = mma(a[i][s], BREG[j][s], acc[AI + i][BJ + j]);
+#define CFD_SYNC_MFMA(VM, MFMAS)                                                       \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+      hwait<VM>();                                                                     \
+      __builtin_amdgcn_s_barrier();                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                               \
+      __builtin_amdgcn_s_setprio(1);                                                   \
+      MFMAS                                                                            \
+      __builtin_amdgcn_s_setprio(0);                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                               \
+      __builtin_amdgcn_s_barrier();
+
+  auto ktile = [&](auto tc, int c) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int NP = G::count(t), J0 = G::first(t);
+    constexpr int t1 = (t + 1) % NT, k1 = (t + 1) / NT, t2 = (t + 2) % NT, k2 = (t + 2) / NT;
+    const int st = (NT & 1) ? ((c + t) & 1) : (t & 1);
+    const int pst = c & 1;
+    const unsigned sa1 = (unsigned)(wto[t1] + min(c + k1, cpt - 1) * 128);
+    const unsigned sa2 = (unsigned)(wto[t2] + min(c + k2, cpt - 1) * 128);
+    const unsigned sp = (unsigned)(min(c + 1, cpt - 1) * 128);
+    const int stoff = st * (2 * HT_BYTES);
+    {   // phase A: A0 x (B rows wc | 4 + wc)
+      const int pp = L0 + toff[t];
+      const int bo = H_ABYTES + pst * G::PATCH + (pp << 7) + ((fq ^ (pp & 7)) << 4);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const char *bb = lds + (bo ^ (s << 6));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b0[j][s] = *(const frag_t *)(bb + j * 2048);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i][s] = *(const frag_t *)(ard[s] + stoff + i * 2048);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b1[j][s] = *(const frag_t *)(bb + H_BROW + j * 2048);
+      }
+#pragma unroll
+      for (int jj = 0; jj < NP; ++jj) issueP(J0 + jj, pst ^ 1, sp);
+      issueA1(st ^ 1, sa1);
+      CFD_SYNC_MFMA(4 + NP, CFD_MFMA(0, 0, b0) CFD_MFMA(0, 2, b1))
+    }
+    {   // phase B: A1 x (the same B fragments)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i][s] = *(const frag_t *)(ard[s] + stoff + HT_BYTES + i * 2048);
+      issueA0(st, sa2);
+      CFD_SYNC_MFMA(4 + NP, CFD_MFMA(4, 0, b0) CFD_MFMA(4, 2, b1))
+    }
+  };
+
+  for (int c = 0; c < cpt; ++c) {
+    ktile(IC<0>{}, c); ktile(IC<1>{}, c); ktile(IC<2>{}, c); ktile(IC<3>{}, c);
+    if constexpr (NT == 9) {
+      ktile(IC<4>{}, c); ktile(IC<5>{}, c); ktile(IC<6>{}, c); ktile(IC<7>{}, c); ktile(IC<8>{}, c);
+    }
+  }
+#undef CFD_SYNC_MFMA
+#undef CFD_MFMA
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  hwait<0>();   // the tail loads must not outlive the workgroup's LDS allocation
+
+  // tile-local row -> output pixel
+  auto out_pixel = [&](int local) -> int64_t {
+    const int qy = ty0 + (local >> 5), qx = tx0 + (local & 31);
+    if (p.kind == CFD_CONVT_K4S2) return ((int64_t)b * p.Ho + 2 * qy + ph) * p.Wo + 2 * qx + pw;
+    return ((int64_t)b * p.Hq + qy) * p.Wq + qx;
+  };
+
+  // ---- fused BatchNorm statistics (as in igemm256_kernel; the tile lies in sample b by construction)
+  if (p.stat_sum) {
+    __syncthreads();   // every wave's LDS-DMA has landed and every fragment read is done: LDS is free
+    float *part = (float *)lds;   // [2][4 wc][256 n]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[i][j][r] + bv[r];
+          t1 += v;
+          t2 = fmaf(v, v, t2);
+        }
+        t1 = row16_sum(t1);
+        t2 = row16_sum(t2);
+        if (fr == 0) {
+          part[(0 * 4 + wc) * 256 + nl + r] = t1;
+          part[(1 * 4 + wc) * 256 + nl + r] = t2;
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int which = tid >> 8, c = tid & 255;
+      const float *pp = part + which * 1024 + c;
+      const float tot = pp[0] + pp[256] + pp[512] + pp[768];
+      atomicAdd((which ? p.stat_sq : p.stat_sum) + (size_t)b * p.Cout + n0 + c, tot);
+    }
+  }
+
+  if (P.stage_out) {
+    // ---- staged epilogue: fragments (bias + activation applied, bf16) -> LDS [pixel][channel] -> whole pixel rows
+    __syncthreads();
+    char *stg = lds + OUT_OFF;
+    auto to_lds = [&](auto with_act) {
+      char *wbase = stg + (wc * 32 + fr) * OUT_ROW + (wr * 64 + fq * 4) * 2;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 v = acc[i][j] + bv;
+          if constexpr (decltype(with_act)::value) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);
+          }
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4 *)(wbase + ((j >> 1) * 128 + (j & 1) * 16) * OUT_ROW + ((i >> 2) * 128 + (i & 3) * 16) * 2) = o;
+        }
+      }
+    };
+    if (act_any) to_lds(std::true_type{}); else to_lds(std::false_type{});
+    __syncthreads();
+    const int half = lane >> 5, ck = lane & 31;   // two pixel rows per wave instruction, 32 chunks of 16 B each
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int ml = wave * 32 + it * 2 + half;
+      const int64_t opix = out_pixel(ml);
+      const uint4 v = *(const uint4 *)(stg + ml * OUT_ROW + ck * 16);
+      *(uint4 *)(p.y + (opix * p.ldy + n0) * 2 + ck * 16) = v;
+    }
+  } else {
+    auto direct_epi = [&](auto mode_c) {
+      constexpr int MODE = decltype(mode_c)::value;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t opix = out_pixel((j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int n = n0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
+          f32x4 v = acc[i][j];
+          if (p.bias) v += *(const f32x4 *)(p.bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);   // ns = 1: identity
+          if (act_sig) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+          }
+          if constexpr (MODE == 1) {
+            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;
+          } else {
+            *(f32x4 *)(p.y + (opix * p.ldy + n) * 4) = v;
+          }
+        }
+      }
+    };
+    if (p.out_bf16) direct_epi(IC<1>{}); else direct_epi(IC<2>{});
+  }
+}
+
+// which layers take this path: bf16, a stride-1 tap grid (3x3 'same' conv, or one sub-pixel class of the transposed
+// 4x4 stride-2 conv), whole 256-channel n tiles, no split-K, a class grid that 8 x 32 tiles cover exactly
+bool igemm256h_eligible(const IgemmParams &p, int dtype) {
+  if (tuning(CFD_TUNE_PATCH) == 0) return false;
+  return dtype == CFD_BF16 && (p.kind == CFD_CONV_K3S1 || p.kind == CFD_CONVT_K4S2) && p.Cout % 256 == 0 &&
+         p.Cin % 64 == 0 && p.split_k == 1 && !p.pool && p.Hq % H_TH == 0 && p.Wq % H_TW == 0 && p.Hi == p.Hq &&
+         p.Wi == p.Wq;
+}
+
+int igemm256h_launch(const IgemmParams &pin, unsigned xbytes, unsigned wbytes, int cls_fast, int stage_out, hipStream_t st) {
+  IgemmHaloParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = pin;
+  const IgemmParams &p = P.g;
+  CFD_REQUIRE(igemm256h_eligible(p, CFD_BF16) && p.ntiles * 256 == p.Cout, "patch-staged kernel: shape not eligible");
+  P.xbytes = xbytes; P.wbytes = wbytes; P.cls_fast = cls_fast; P.stage_out = stage_out;
+  P.tpr = p.Wq / H_TW;
+  P.tps = (p.Hq / H_TH) * P.tpr;
+  CFD_REQUIRE((int64_t)P.tps * p.B == p.mtiles && (int64_t)p.mtiles * p.ntiles * p.nclass == p.nblocks,
+              "patch-staged kernel: tile count %d does not match the 8 x 32 tiling", p.mtiles);
+  const int ph_rows = H_TH + (p.ntaps == 9 ? 2 : 1);
+  CFD_REQUIRE(p.ntaps == 9 || p.ntaps == 4, "patch-staged kernel: %d taps", p.ntaps);
+  for (int cls = 0; cls < p.nclass; ++cls) {
+    int dy[9], dx[9], wt[9], dymin = 1 << 20, dxmin = 1 << 20;
+    for (int t = 0; t < p.ntaps; ++t) {
+      tap_geom(p.kind, cls >> 1, cls & 1, t, dy[t], dx[t], wt[t]);
+      dymin = dy[t] < dymin ? dy[t] : dymin;
+      dxmin = dx[t] < dxmin ? dx[t] : dxmin;
+    }
+    P.dymin[cls] = dymin; P.dxmin[cls] = dxmin;
+    for (int t = 0; t < p.ntaps; ++t) {
+      CFD_REQUIRE(dy[t] - dymin + H_TH <= ph_rows && dx[t] - dxmin + H_TW <= H_PW, "patch-staged kernel: tap outside the patch");
+      P.toff[cls][t] = (dy[t] - dymin) * H_PW + (dx[t] - dxmin);
+      P.wtoff[cls][t] = wt[t] * p.Cin * 2;
+    }
+  }
+  if (p.ntaps == 9) {
+    static bool done = false;
+    if (!done) {
+      CFD_HIP(hipFuncSetAttribute((const void *)igemm256h_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeo<9>::LDS));
+      done = true;
+    }
+    hipLaunchKernelGGL(igemm256h_kernel<9>, dim3(p.nblocks), dim3(512), HaloGeo<9>::LDS, st, P);
+  } else {
+    static bool done = false;
+    if (!done) {
+      CFD_HIP(hipFuncSetAttribute((const void *)igemm256h_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeo<4>::LDS));
+      done = true;
+    }
+    hipLaunchKernelGGL(igemm256h_kernel<4>, dim3(p.nblocks), dim3(512), HaloGeo<4>::LDS, st, P);
+  }
+  CFD_LAUNCH_CHECK();
+  return CFD_OK;
+}
+
+}  // namespace cfd

@@ -148,6 +148,51 @@ def test_conv_forward_igemm256_persistent(kind, B, H, W, cin, cout, split_k, pd)
     _igemm256_case(kind, B, H, W, cin, cout, split_k, torch.bfloat16, pd)
 
 
+@pytest.mark.parametrize("kind,B,H,W,cin,cout", [
+    ("k3s1", 2, 16, 32, 64, 256),       # one channel chunk: the patch of "chunk 1" is never read
+    ("k3s1", 1, 8, 64, 192, 512),       # three chunks (stage parity flips per chunk with 9 taps), two tiles per row, two n tiles
+    ("k3s1", 3, 24, 96, 128, 256),      # 3 x 3 tiles per sample on a grid that is no power of two
+    ("convT", 2, 8, 32, 128, 256),      # four sub-pixel classes, two chunks
+    ("convT", 1, 16, 64, 320, 256),     # five chunks
+    ("convT", 2, 8, 64, 64, 512),       # one chunk, two n tiles
+])
+def test_conv_forward_patch_staged(kind, B, H, W, cin, cout):
+    """igemm256h_kernel (activation operand staged once per channel chunk as an input patch; bf16 3x3 and transposed 4x4
+    on whole 8 x 32 tiles) against the oracle, against the per-tap kernel, and reading a channel slice of a wider input"""
+    from cfd_amd import ops
+    dtype, dev = torch.bfloat16, "cuda"
+    ops.set_tuning(ops.TUNE_NTILE, 256)              # (few tiles: the heuristic would pick the 128-wide n tile)
+    try:
+        _igemm256_case(kind, B, H, W, cin, cout, 1, dtype, -1)
+    finally:
+        ops.set_tuning(ops.TUNE_NTILE, -1)
+    x = q(rnd((B, H, W, cin), 1), dtype)
+    bias = rnd((cout,), 3, 0.1)
+    if kind == "convT":
+        wk = q(rnd((4, 4, cout, cin), 2, 0.05), dtype)
+        wp, code = ops.pack_convT_weight(wk.to(dev), dtype), ops.CONVT_K4S2
+    else:
+        wk = q(rnd((3, 3, cin, cout), 2, 0.05), dtype)
+        wp, code = ops.pack_conv_weight(wk.to(dev), dtype), ops.CONV_K3S1
+    wide = torch.full((B, H, W, cin + 128), 3.0, dtype=dtype, device=dev)
+    wide[..., 64:64 + cin] = x.to(dev).to(dtype)
+    ops.set_tuning(ops.TUNE_IGEMM256, 1)
+    ops.set_tuning(ops.TUNE_NTILE, 256)
+    try:
+        a = ops.conv_forward(wide[..., 64:64 + cin], wp, bias.to(dev), code, cout, out_dtype=torch.float32, split_k=1)
+        ops.set_tuning(ops.TUNE_PATCH, 0)
+        b = ops.conv_forward(x.to(dev).to(dtype), wp, bias.to(dev), code, cout, out_dtype=torch.float32, split_k=1)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning(ops.TUNE_IGEMM256, -1)
+        ops.set_tuning(ops.TUNE_PATCH, -1)
+        ops.set_tuning(ops.TUNE_NTILE, -1)
+    # (one chunk: both kernels add the same products in the same order; more: chunk-major against tap-major K order,
+    #  which also shows that the two launches really ran different kernels)
+    assert torch.equal(a, b) == (cin == 64)
+    assert relerr(a.cpu(), b.cpu()) <= 1e-5          # same products, another summation order (chunk-major K)
+
+
 def _igemm256_case(kind, B, H, W, cin, cout, split_k, dtype, pd):
     """the 256x256 ping-pong kernel (igemm256.hip; bf16 and exact-f32 MFMA), forced on, against the oracle; bias +
     LeakyReLU fused, output written into a channel slice of a wider buffer"""
@@ -316,13 +361,14 @@ def test_bn_act(B, H, W, C, drop, dtype):
 
 
 @pytest.mark.parametrize("dtype,force256", [(torch.float32, 0), (torch.float32, 1), (torch.bfloat16, 0),
-                                            (torch.bfloat16, 1), (torch.bfloat16, 37)])
+                                            (torch.bfloat16, 1), (torch.bfloat16, 37), (torch.bfloat16, 256)])
 @pytest.mark.parametrize("kind,B,H,W,cin,cout,drop", [
     ("k4s2", 3, 32, 32, 64, 256, False),    # 256 output pixels per sample: one tile per sample
     ("k4s2", 16, 32, 32, 64, 256, False),   # 16 tiles: two per workgroup in the persistent kernel (force256 = 37)
     ("k4s2", 2, 32, 64, 64, 256, False),    # 512 per sample
     ("convT", 2, 16, 16, 64, 256, True),    # class grid 256 per sample, dropout (RNG mode)
     ("k4s2", 2, 32, 32, 64, 128, False),    # Cout = 128: 128-wide n tile in both kernels
+    ("convT", 2, 16, 32, 128, 256, True),   # whole 8 x 32 tiles: the patch-staged kernel when the 256-wide path is forced
 ])
 def test_conv_stats_bn_apply(kind, B, H, W, cin, cout, drop, dtype, force256):
     """BatchNorm statistics fused into the conv epilogue + bn_apply == conv -> oracle BatchNorm (+dropout, acts)"""
@@ -343,7 +389,8 @@ def test_conv_stats_bn_apply(kind, B, H, W, cin, cout, drop, dtype, force256):
     ref = O.batchnorm(pre, p, "l", True, True, st)
     Bo, Ho, Wo, _ = pre.shape
     ops.set_tuning(ops.TUNE_IGEMM256, 1 if force256 >= 36 else force256)
-    ops.set_tuning(ops.TUNE_IGEMM256_PD, force256 if force256 >= 36 else -1)   # 36 / 37: the persistent kernel
+    ops.set_tuning(ops.TUNE_IGEMM256_PD, force256 if force256 in (36, 37) else -1)   # 36 / 37: the persistent kernel
+    ops.set_tuning(ops.TUNE_NTILE, 256 if force256 == 256 else -1)                   # 256: whole 256-wide n tiles
     try:
         stats = (torch.zeros((B, cout), device=dev), torch.zeros((B, cout), device=dev))
         raw = torch.empty(tuple(pre.shape), dtype=torch.float32, device=dev)
@@ -352,6 +399,7 @@ def test_conv_stats_bn_apply(kind, B, H, W, cin, cout, drop, dtype, force256):
     finally:
         ops.set_tuning(ops.TUNE_IGEMM256, -1)
         ops.set_tuning(ops.TUNE_IGEMM256_PD, -1)
+        ops.set_tuning(ops.TUNE_NTILE, -1)
     assert fused, "shape was expected to be fusable"
     n = Ho * Wo
     torch.cuda.synchronize()
