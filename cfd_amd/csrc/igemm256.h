@@ -43,8 +43,9 @@ __device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) {
 }
 
 // igemm256h.hip: patch-staged variant (bf16, 3x3 stride 1 and the transposed 4x4 stride 2, no split-K).  `p` as prepared
-// by igemm256_launch (mtiles / ntiles / nblocks for 256 x 256 tiles).
-bool igemm256h_eligible(const IgemmParams &p, int dtype);
-int igemm256h_launch(const IgemmParams &p, unsigned xbytes, unsigned wbytes, int cls_fast, int stage_out, hipStream_t st);
+// by igemm256_launch (mtiles / ntiles / nblocks for 256-row m tiles and `ntile`-wide n tiles).
+bool igemm256h_eligible(const IgemmParams &p, int dtype, int ntile);
+int igemm256h_launch(const IgemmParams &p, int ntile, unsigned xbytes, unsigned wbytes, int cls_fast, int stage_out,
+                     hipStream_t st);
 
 }  // namespace cfd

@@ -1167,8 +1167,8 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   const size_t shmem = (P.stage_out || p.pool) ? (size_t)OUT_LDS : (size_t)2 * ST_BYTES;
   const int pdt = tuning(CFD_TUNE_IGEMM256_PD);
   // stride-1 tap grids on whole 8 x 32 pixel tiles: the activation operand is staged once per channel chunk (igemm256h.hip)
-  if (pdt < 0 && ntile == 256 && igemm256h_eligible(p, dtype))
-    return igemm256h_launch(p, P.xbytes, P.wbytes, P.cls_fast, P.stage_out, st);
+  if (pdt < 0 && igemm256h_eligible(p, dtype, ntile))
+    return igemm256h_launch(p, ntile, P.xbytes, P.wbytes, P.cls_fast, P.stage_out, st);
   // persistent form (igemm256p_kernel): bf16, 256-wide n tiles, more tiles than CUs, every K range even
   // (CFD_TUNE_IGEMM256_PD: 36 forces it where legal, 26 forbids it)
   const int ktiles_all = p.ntaps * p.cpt;

@@ -22,7 +22,7 @@
 //     outside the image get an out-of-range voffset, which the hardware zero-fills.
 //   * vmcnt bookkeeping: phase A of K tile k issues [patch loads n_t] + A1(k+1), phase B issues A0(k+2); both phases end
 //     with vmcnt(4 + n_t), which retires A1(k) / A0(k+1) respectively.
-//   * no split-K, no pooled epilogue (the host keeps those layers on igemm256_kernel).
+//   * no split-K (the host keeps those layers on igemm256_kernel); the pooled epilogue works on the 8 x 32 tile.
 #include "common.h"
 #include "igemm.h"
 #include "igemm256.h"
@@ -280,7 +280,51 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
     }
   }
 
-  if (P.stage_out) {
+  if (p.pool) {
+    // ---- pooled epilogue (conv + bias + monotone activation + 2x2 max-pool, as igemm256_kernel's, on the 8 x 32 tile:
+    // 4 x 16 pooled pixels, every pooling window inside the tile): fragments -> LDS [tile pixel][channel], then each
+    // pooled pixel takes the maximum of its four rows and leaves as one 512-B run
+    __syncthreads();
+    char *stg = lds + OUT_OFF;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int local = (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fr;
+        f32x4 v = acc[i][j] + bv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *(bf16x4 *)(stg + local * OUT_ROW + nl * 2) = o;
+      }
+    }
+    __syncthreads();
+    const int half = lane >> 5, ck = lane & 31;
+    auto mx = [](unsigned u0, unsigned u1, unsigned u2, unsigned u3) {
+      // two bf16 per word: compare as floats (a bf16 is the high half of its f32), repack the winners' bits
+      const float l = fmaxf(fmaxf(__uint_as_float(u0 << 16), __uint_as_float(u1 << 16)),
+                            fmaxf(__uint_as_float(u2 << 16), __uint_as_float(u3 << 16)));
+      const float g = fmaxf(fmaxf(__uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 & 0xffff0000u)),
+                            fmaxf(__uint_as_float(u2 & 0xffff0000u), __uint_as_float(u3 & 0xffff0000u)));
+      return (__float_as_uint(g) & 0xffff0000u) | (__float_as_uint(l) >> 16);
+    };
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = wave * 8 + it * 2 + half;   // pooled pixel inside the tile: row q / 16, column q % 16
+      const int py = q >> 4, px = q & 15;
+      const char *s0 = stg + (py * 64 + px * 2) * OUT_ROW + ck * 16;
+      const uint4 a4 = *(const uint4 *)s0, b4 = *(const uint4 *)(s0 + OUT_ROW);
+      const uint4 c4 = *(const uint4 *)(s0 + 32 * OUT_ROW), d4 = *(const uint4 *)(s0 + 33 * OUT_ROW);
+      uint4 o;
+      o.x = mx(a4.x, b4.x, c4.x, d4.x); o.y = mx(a4.y, b4.y, c4.y, d4.y);
+      o.z = mx(a4.z, b4.z, c4.z, d4.z); o.w = mx(a4.w, b4.w, c4.w, d4.w);
+      const int64_t opix = ((int64_t)b * (p.Hq >> 1) + (ty0 >> 1) + py) * (p.Wq >> 1) + (tx0 >> 1) + px;
+      *(uint4 *)(p.y + (opix * p.ldy + n0) * 2 + ck * 16) = o;
+    }
+  } else if (P.stage_out) {
     // ---- staged epilogue: fragments (bias + activation applied, bf16) -> LDS [pixel][channel] -> whole pixel rows
     __syncthreads();
     char *stg = lds + OUT_OFF;
@@ -343,21 +387,261 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 128(n) x 256(m) variant (Cout = 128 mod 256, and the small-M layers the host gives the 128-wide n tile): the machinery of
+// igemm128n_kernel -- ONE phase of 32 MFMAs per K tile, a three-stage ring for the weight half tile (48 KiB) -- with the
+// patch in place of the two gathered B half tiles.  Per K tile a wave issues 2 weight loads + at most 2 patch loads
+// instead of 6 loads, which is what lets the memory cluster of one wave group fit under the MFMA cluster of the other.
+//   wave (wr, wc) owns n rows wr*64 + [0,64) and tile rows 2 wc, 2 wc + 1 (four 16-pixel runs); the two rows' swizzle
+//   keys differ (row pitch 34 = 2 mod 8), so there is one lane base address per row and tap.
+//   phase k: read stage k % 3 and the patch; issue [patch loads n_t] + A(k+2) into stage (k+2) % 3; vmcnt(2 + n_t)
+//   (A(k+1) landed; in the chunk's last K tile n_t = 0, so the whole next patch has landed too); barrier; 32 MFMAs; barrier.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int H3_ABYTES = 3 * HT_BYTES;
+
+template <int NT> struct HaloGeo3 : HaloGeo<NT> {
+  static constexpr int LDS = H3_ABYTES + 2 * HaloGeo<NT>::PATCH;
+};
+
+template <int N> __device__ __forceinline__ void hwait3() {
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else static_assert(N < 0, "unsupported vmcnt");
+}
+
+template <int NT>
+__global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  using G = HaloGeo3<NT>;
+  const IgemmParams &p = P.g;
+  typedef bf16x8 frag_t;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const float act_ns = act_neg_scale(p.act, p.slope);
+  const bool act_sig = p.act == CFD_ACT_SIGMOID;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = p.nblocks, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt = bid % p.ntiles; bid /= p.ntiles;
+  int mt, cls;
+  if (P.cls_fast) { cls = bid % p.nclass; bid /= p.nclass; mt = bid; }
+  else { mt = bid % p.mtiles; bid /= p.mtiles; cls = bid; }
+  const int ph = cls >> 1, pw = cls & 1;
+  const int n0 = nt * 128;
+  const int b = mt / P.tps;
+  const int trem = mt - b * P.tps;
+  const int tyi = trem / P.tpr;
+  const int ty0 = tyi * H_TH, tx0 = (trem - tyi * P.tpr) * H_TW;
+  const int cpt = p.cpt;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)P.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)P.wbytes, 0x00020000);
+
+  int toff[NT], wto[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    toff[t] = __builtin_amdgcn_readfirstlane(P.toff[cls][t]);
+    wto[t] = __builtin_amdgcn_readfirstlane(P.wtoff[cls][t]);
+  }
+
+  const int lrow = lane >> 3;
+  const int chunk = (lane & 7) ^ lrow;
+  unsigned avoff[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) avoff[r] = (unsigned)(((n0 + r * 64 + wave * 8 + lrow) * p.Kw + chunk * 8) * 2);
+  unsigned pvoff[G::PPW];
+  {
+    const int py0 = ty0 + P.dymin[cls], px0 = tx0 + P.dxmin[cls];
+#pragma unroll
+    for (int j = 0; j < G::PPW; ++j) {
+      const int q = min(j * 8 + wave, G::NPI - 1);
+      const int pp = q * 8 + lrow;
+      const int py = pp / H_PW, px = pp - py * H_PW;
+      const int y = py0 + py, x = px0 + px;
+      const bool ok = pp < G::PP && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+      pvoff[j] = ok ? (unsigned)((((b * p.Hi + y) * p.Wi + x) * p.ldx + chunk * 8) * 2) : OOB;
+    }
+  }
+
+  char *const ldsw = lds + wave * 1024;
+  auto issueA = [&](int st, unsigned sa) {
+    char *dst = ldsw + st * HT_BYTES;
+    bload16(wrs, avoff[0], sa, dst); bload16(wrs, avoff[1], sa, dst + 8192);
+  };
+  auto issueP = [&](int j, int pst, unsigned sp) {
+    const int q = min(j * 8 + wave, G::NPI - 1);
+    bload16(xrs, pvoff[j], sp, lds + H3_ABYTES + pst * G::PATCH + q * 1024);
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int laneoff = fr * 128 + ((fq ^ (fr & 7)) << 4);
+  const char *ard[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) ard[s] = lds + ((wr * 64 * 128 + laneoff) ^ (s << 6));
+  const int L0 = 2 * wc * H_PW + fr;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int j = 0; j < G::PPW; ++j) issueP(j, 0, 0u);
+  issueA(0, (unsigned)wto[0]);
+  issueA(1, (unsigned)(wto[1 % NT] + min(1 / NT, cpt - 1) * 128));
+  hwait3<2>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+
+  frag_t a[4][2], bf[4][2];
+  int stg = 0;   // ring stage of the current K tile (NT = 4; with 9 taps it is t % 3)
+
+  auto ktile = [&](auto tc, int c) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int NP = G::count(t), J0 = G::first(t);
+    constexpr int t2 = (t + 2) % NT, k2 = (t + 2) / NT;
+    int st;
+    if constexpr (NT % 3 == 0) st = t % 3; else st = stg;
+    const int st2 = st == 0 ? 2 : st - 1;   // (st + 2) % 3
+    const int pst = c & 1;
+    const unsigned sa2 = (unsigned)(wto[t2] + min(c + k2, cpt - 1) * 128);
+    const unsigned sp = (unsigned)(min(c + 1, cpt - 1) * 128);
+    const int pp0 = L0 + toff[t], pp1 = pp0 + H_PW;
+    const int pb = H3_ABYTES + pst * G::PATCH;
+    const int bo0 = pb + (pp0 << 7) + ((fq ^ (pp0 & 7)) << 4);
+    const int bo1 = pb + (pp1 << 7) + ((fq ^ (pp1 & 7)) << 4);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const char *b0p = lds + (bo0 ^ (s << 6)), *b1p = lds + (bo1 ^ (s << 6));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i][s] = *(const frag_t *)(ard[s] + st * HT_BYTES + i * 2048);
+      bf[0][s] = *(const frag_t *)(b0p);
+      bf[1][s] = *(const frag_t *)(b0p + 2048);
+      bf[2][s] = *(const frag_t *)(b1p);
+      bf[3][s] = *(const frag_t *)(b1p + 2048);
+    }
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) issueP(J0 + jj, pst ^ 1, sp);
+    issueA(st2, sa2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    hwait3<2 + NP>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mma(a[i][s], bf[j][s], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if constexpr (NT % 3 != 0) stg = stg == 2 ? 0 : stg + 1;
+  };
+
+  for (int c = 0; c < cpt; ++c) {
+    ktile(IC<0>{}, c); ktile(IC<1>{}, c); ktile(IC<2>{}, c); ktile(IC<3>{}, c);
+    if constexpr (NT == 9) {
+      ktile(IC<4>{}, c); ktile(IC<5>{}, c); ktile(IC<6>{}, c); ktile(IC<7>{}, c); ktile(IC<8>{}, c);
+    }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  hwait<0>();
+
+  auto out_pixel = [&](int local) -> int64_t {
+    const int qy = ty0 + (local >> 5), qx = tx0 + (local & 31);
+    if (p.kind == CFD_CONVT_K4S2) return ((int64_t)b * p.Ho + 2 * qy + ph) * p.Wo + 2 * qx + pw;
+    return ((int64_t)b * p.Hq + qy) * p.Wq + qx;
+  };
+
+  if (p.stat_sum) {
+    __syncthreads();
+    float *part = (float *)lds;   // [2][4 wc][128 n]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nl = wr * 64 + i * 16 + fq * 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[i][j][r] + bv[r];
+          t1 += v;
+          t2 = fmaf(v, v, t2);
+        }
+        t1 = row16_sum(t1);
+        t2 = row16_sum(t2);
+        if (fr == 0) {
+          part[(0 * 4 + wc) * 128 + nl + r] = t1;
+          part[(1 * 4 + wc) * 128 + nl + r] = t2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int which = tid >> 7, c = tid & 127;
+      const float *pp = part + which * 512 + c;
+      const float tot = pp[0] + pp[128] + pp[256] + pp[384];
+      atomicAdd((which ? p.stat_sq : p.stat_sum) + (size_t)b * p.Cout + n0 + c, tot);
+    }
+  }
+
+  auto direct_epi = [&](auto mode_c) {
+    constexpr int MODE = decltype(mode_c)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t opix = out_pixel(wc * 64 + j * 16 + fr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wr * 64 + i * 16 + fq * 4;
+        f32x4 v = acc[i][j];
+        if (p.bias) v += *(const f32x4 *)(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);
+        if (act_sig) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+        }
+        if constexpr (MODE == 1) {
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;
+        } else {
+          *(f32x4 *)(p.y + (opix * p.ldy + n) * 4) = v;
+        }
+      }
+    }
+  };
+  if (p.out_bf16) direct_epi(IC<1>{}); else direct_epi(IC<2>{});
+}
+
 // which layers take this path: bf16, a stride-1 tap grid (3x3 'same' conv, or one sub-pixel class of the transposed
 // 4x4 stride-2 conv), whole 256-channel n tiles, no split-K, a class grid that 8 x 32 tiles cover exactly
-bool igemm256h_eligible(const IgemmParams &p, int dtype) {
+bool igemm256h_eligible(const IgemmParams &p, int dtype, int ntile) {
   if (tuning(CFD_TUNE_PATCH) == 0) return false;
-  return dtype == CFD_BF16 && (p.kind == CFD_CONV_K3S1 || p.kind == CFD_CONVT_K4S2) && p.Cout % 256 == 0 &&
-         p.Cin % 64 == 0 && p.split_k == 1 && !p.pool && p.Hq % H_TH == 0 && p.Wq % H_TW == 0 && p.Hi == p.Hq &&
+  return dtype == CFD_BF16 && (p.kind == CFD_CONV_K3S1 || p.kind == CFD_CONVT_K4S2) && p.Cout % ntile == 0 &&
+         p.Cin % 64 == 0 && p.split_k == 1 && (!p.pool || (ntile == 256 && p.nclass == 1 && p.out_bf16)) && p.Hq % H_TH == 0 && p.Wq % H_TW == 0 && p.Hi == p.Hq &&
          p.Wi == p.Wq;
 }
 
-int igemm256h_launch(const IgemmParams &pin, unsigned xbytes, unsigned wbytes, int cls_fast, int stage_out, hipStream_t st) {
+int igemm256h_launch(const IgemmParams &pin, int ntile, unsigned xbytes, unsigned wbytes, int cls_fast, int stage_out,
+                     hipStream_t st) {
   IgemmHaloParams P;
   memset(&P, 0, sizeof(P));
   P.g = pin;
   const IgemmParams &p = P.g;
-  CFD_REQUIRE(igemm256h_eligible(p, CFD_BF16) && p.ntiles * 256 == p.Cout, "patch-staged kernel: shape not eligible");
+  CFD_REQUIRE((ntile == 128 || ntile == 256) && igemm256h_eligible(p, CFD_BF16, ntile) && p.ntiles * ntile == p.Cout,
+              "patch-staged kernel: shape not eligible");
   P.xbytes = xbytes; P.wbytes = wbytes; P.cls_fast = cls_fast; P.stage_out = stage_out;
   P.tpr = p.Wq / H_TW;
   P.tps = (p.Hq / H_TH) * P.tpr;
@@ -379,21 +663,21 @@ int igemm256h_launch(const IgemmParams &pin, unsigned xbytes, unsigned wbytes, i
       P.wtoff[cls][t] = wt[t] * p.Cin * 2;
     }
   }
-  if (p.ntaps == 9) {
-    static bool done = false;
-    if (!done) {
-      CFD_HIP(hipFuncSetAttribute((const void *)igemm256h_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeo<9>::LDS));
-      done = true;
-    }
-    hipLaunchKernelGGL(igemm256h_kernel<9>, dim3(p.nblocks), dim3(512), HaloGeo<9>::LDS, st, P);
+#define CFD_LAUNCH_H(KERNEL, GEO)                                                                                   \
+  do {                                                                                                              \
+    static bool done_ = false;                                                                                      \
+    if (!done_) {                                                                                                   \
+      CFD_HIP(hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, GEO::LDS));     \
+      done_ = true;                                                                                                 \
+    }                                                                                                               \
+    hipLaunchKernelGGL(KERNEL, dim3(p.nblocks), dim3(512), GEO::LDS, st, P);                                        \
+  } while (0)
+  if (ntile == 256) {
+    if (p.ntaps == 9) CFD_LAUNCH_H(igemm256h_kernel<9>, HaloGeo<9>); else CFD_LAUNCH_H(igemm256h_kernel<4>, HaloGeo<4>);
   } else {
-    static bool done = false;
-    if (!done) {
-      CFD_HIP(hipFuncSetAttribute((const void *)igemm256h_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeo<4>::LDS));
-      done = true;
-    }
-    hipLaunchKernelGGL(igemm256h_kernel<4>, dim3(p.nblocks), dim3(512), HaloGeo<4>::LDS, st, P);
+    if (p.ntaps == 9) CFD_LAUNCH_H(igemm128nh_kernel<9>, HaloGeo3<9>); else CFD_LAUNCH_H(igemm128nh_kernel<4>, HaloGeo3<4>);
   }
+#undef CFD_LAUNCH_H
   CFD_LAUNCH_CHECK();
   return CFD_OK;
 }

@@ -101,6 +101,7 @@ def test_conv_forward_igemm256(kind, B, H, W, cin, cout, split_k, dtype, pd):
     ("k3s1", 2, 8, 256, 64, 256, "leaky"),    # two 128-column blocks per image row
     ("k3s1", 3, 4, 128, 64, 512, "relu"),     # one block per row (tile = two whole rows), two n tiles
     ("k4s1", 1, 6, 384, 64, 256, "none"),     # three blocks per row, asymmetric 'same' padding, non-power-of-two grid
+    ("k3s1", 2, 16, 128, 128, 512, "leaky"),  # bf16: the patch-staged kernel's pooled epilogue (8 x 32 tiles), two chunks
 ])
 def test_conv_forward_pool2(kind, B, H, W, cin, cout, act, dtype):
     """conv + bias + activation + MaxPooling2D(2x2) in one launch (igemm256's pooled epilogue: 2-row x 128-column m
@@ -155,13 +156,18 @@ def test_conv_forward_igemm256_persistent(kind, B, H, W, cin, cout, split_k, pd)
     ("convT", 2, 8, 32, 128, 256),      # four sub-pixel classes, two chunks
     ("convT", 1, 16, 64, 320, 256),     # five chunks
     ("convT", 2, 8, 64, 64, 512),       # one chunk, two n tiles
+    ("k3s1", 2, 8, 32, 64, 128),        # Cout = 128: the 128(n) variant only (DeltaP g3's shape class)
+    ("convT", 1, 8, 32, 192, 384),      # three 128-wide n tiles, three chunks (ring stage runs on across chunks)
 ])
-def test_conv_forward_patch_staged(kind, B, H, W, cin, cout):
+@pytest.mark.parametrize("ntile", [256, 128])
+def test_conv_forward_patch_staged(kind, B, H, W, cin, cout, ntile):
     """igemm256h_kernel (activation operand staged once per channel chunk as an input patch; bf16 3x3 and transposed 4x4
     on whole 8 x 32 tiles) against the oracle, against the per-tap kernel, and reading a channel slice of a wider input"""
     from cfd_amd import ops
     dtype, dev = torch.bfloat16, "cuda"
-    ops.set_tuning(ops.TUNE_NTILE, 256)              # (few tiles: the heuristic would pick the 128-wide n tile)
+    if cout % ntile:
+        pytest.skip("Cout is no multiple of this n tile")
+    ops.set_tuning(ops.TUNE_NTILE, ntile)            # igemm256h_kernel / igemm128nh_kernel
     try:
         _igemm256_case(kind, B, H, W, cin, cout, 1, dtype, -1)
     finally:
@@ -177,7 +183,7 @@ def test_conv_forward_patch_staged(kind, B, H, W, cin, cout):
     wide = torch.full((B, H, W, cin + 128), 3.0, dtype=dtype, device=dev)
     wide[..., 64:64 + cin] = x.to(dev).to(dtype)
     ops.set_tuning(ops.TUNE_IGEMM256, 1)
-    ops.set_tuning(ops.TUNE_NTILE, 256)
+    ops.set_tuning(ops.TUNE_NTILE, ntile)
     try:
         a = ops.conv_forward(wide[..., 64:64 + cin], wp, bias.to(dev), code, cout, out_dtype=torch.float32, split_k=1)
         ops.set_tuning(ops.TUNE_PATCH, 0)
