@@ -29,6 +29,9 @@ os.makedirs(dst, exist_ok=True)
 
 def short(name):
     name = name.replace("void ", "")
+    for k in ("igemm256h_kernel", "igemm128nh_kernel"):      # patch-staged kernels: bf16 only, templated on the tap count
+        if k in name:
+            return k + "<bf16>"
     for k in ("igemm256_kernel", "igemm128n_kernel", "igemm_kernel", "wgrad256_kernel", "wgrad_slab_reduce_kernel",
               "conv_first_wgrad_kernel", "wgrad_kernel", "bn_apply_kernel", "bn_act_bwd_split_kernel", "bn_act_bwd_kernel", "bn_act_kernel",
               "conv_first_kernel", "adam_kernel", "splitk_epilogue_kernel", "tapgemm",
