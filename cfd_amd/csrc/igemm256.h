@@ -27,6 +27,7 @@ struct Igemm256Params {
 constexpr int OUT_ROW = 528;               // 512 B of channels + 16 B pad (bank spread of the fragment writes)
 constexpr int OUT_OFF = 8192;              // after the statistics partials
 constexpr int OUT_LDS = OUT_OFF + 256 * OUT_ROW;
+constexpr int BIAS256_OFF = OUT_LDS;       // igemm256_kernel: the n tile's bias (1 KiB) sits after everything else
 
 __device__ __forceinline__ void bload16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char *lds_dst) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_dst, 16, (int)voff,

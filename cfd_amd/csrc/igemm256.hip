@@ -214,6 +214,13 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   CFD_TSTAMP(5)
+  // the n tile's bias goes to LDS with the very first load (every wave issues the same 1 KiB so the vmcnt bookkeeping
+  // stays uniform; it is the oldest load and retires with the first wait): fetched from global memory in the epilogue it
+  // cost a round trip per tile that nothing overlapped (~1 us: P d5 447 -> 463 us, DeltaP g3 203 -> 221 with a bias)
+  if (p.bias) {
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, p.Cout * 4, 0x00020000);
+    bload16(brs, (unsigned)(n0 * 4 + lane * 16), 0u, lds + BIAS256_OFF);
+  }
   // ---- prologue: H0 .. H(PD-1)   (NPH == 2: H0 .. H5, and H0..H2 must have landed)
   constexpr int PRO = NPH == 2 ? 6 : PD;
 #pragma unroll
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
     for (int i = 0; i < 8; ++i) {
       const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+      if (p.bias) bv = *(const f32x4 *)(lds + BIAS256_OFF + nl * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float t1 = 0.f, t2 = 0.f;
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
         const int i = h * (8 / NPASS) + ii;
         const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+        if (p.bias) bv = *(const f32x4 *)(lds + BIAS256_OFF + nl * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int local = (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fr;
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
       for (int i = 0; i < 8; ++i) {
         const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+        if (p.bias) bv = *(const f32x4 *)(lds + BIAS256_OFF + nl * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           f32x4 v = acc[i][j] + bv;
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
       if constexpr (MODE == 0) {          // split-K slab: raw partial sums
         *(f32x4 *)(p.ws + ((int64_t)sk * p.B * p.Ho * p.Wo + opix) * p.Cout + n) = v;
       } else {
-        if (p.bias) v += *(const f32x4 *)(p.bias + n);
+        if (p.bias) v += *(const f32x4 *)(lds + BIAS256_OFF + (n - n0) * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);   // ns = 1: identity
         if (act_sig) {
@@ -856,6 +863,7 @@ __global__ __launch_bounds__(512, 2) void igemm256p_kernel(Igemm256Params P) {
 //   32 MFMAs; barrier.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int ST3_BYTES = 3 * HT_BYTES;
+constexpr int BIAS128N_OFF = 3 * ST3_BYTES;   // 1 KiB after the three stages
 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
@@ -965,6 +973,10 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  if (p.bias) {   // (as in igemm256_kernel: the n tile's bias rides to LDS ahead of the first loads)
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, p.Cout * 4, 0x00020000);
+    bload16(brs, (unsigned)(n0 * 4 + lane * 16), 0u, lds + BIAS128N_OFF);
+  }
   issue_ktile(0);
   issue_ktile(1);
   wait_vmcnt<6>();   // K tile 0 landed
@@ -1015,7 +1027,7 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
     for (int i = 0; i < 4; ++i) {
       const int nl = wr * 64 + i * 16 + fq * 4;
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+      if (p.bias) bv = *(const f32x4 *)(lds + BIAS128N_OFF + nl * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float t1 = 0.f, t2 = 0.f;
@@ -1064,7 +1076,7 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
       if constexpr (MODE == 0) {
         *(f32x4 *)(p.ws + ((int64_t)sk * p.B * p.Ho * p.Wo + opix) * p.Cout + n) = v;
       } else {
-        if (p.bias) v += *(const f32x4 *)(p.bias + n);
+        if (p.bias) v += *(const f32x4 *)(lds + BIAS128N_OFF + (n - n0) * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);
         if (act_sig) {
@@ -1164,7 +1176,7 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
     CFD_REQUIRE(ntile == 256 && p.nclass == 1 && p.split_k == 1 && !p.stat_sum && p.M % 256 == 0, "pooled epilogue: bad launch");
     P.stage_out = 0;
   }
-  const size_t shmem = (P.stage_out || p.pool) ? (size_t)OUT_LDS : (size_t)2 * ST_BYTES;
+  const size_t shmem = (size_t)BIAS256_OFF + 1024;   // stages / staged output tile, then the n tile's bias
   const int pdt = tuning(CFD_TUNE_IGEMM256_PD);
   // stride-1 tap grids on whole 8 x 32 pixel tiles: the activation operand is staged once per channel chunk (igemm256h.hip)
   if (pdt < 0 && igemm256h_eligible(p, dtype, ntile))
@@ -1194,13 +1206,13 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
     static bool done_ = false;                                                                                      \
     if (!done_) {                                                                                                   \
       CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<__VA_ARGS__>,                                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)OUT_LDS));                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)BIAS256_OFF + 1024));           \
       done_ = true;                                                                                                 \
     }                                                                                                               \
     hipLaunchKernelGGL((igemm256_kernel<__VA_ARGS__>), dim3(p.nblocks), dim3(512), shmem, st, P);                   \
   } while (0)
   if (ntile == 128) {
-    const size_t shmem3 = 3 * ST3_BYTES;
+    const size_t shmem3 = BIAS128N_OFF + 1024;
     static bool done3 = false;
     if (!done3) {
       CFD_HIP(hipFuncSetAttribute((const void *)igemm128n_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem3));

@@ -41,11 +41,12 @@ template <int NT> struct HaloGeo {
   static constexpr int PPW = (NPI + 7) / 8;      // ... per wave
   static constexpr int PER = (PPW + NT - 2) / (NT - 1);   // per K tile, so that the chunk's last K tile carries none
   static constexpr int PATCH = NPI * 1024;
-  static constexpr int LDS = H_ABYTES + 2 * PATCH;
+  static constexpr int BIAS_OFF = H_ABYTES + 2 * PATCH;   // the n tile's bias (1 KiB), fetched with the first loads
+  static constexpr int LDS = BIAS_OFF + 1024;
   static constexpr int first(int t) { return t * PER < PPW ? t * PER : PPW; }
   static constexpr int count(int t) { return first(t + 1) - first(t); }
   static_assert(first(NT - 1) == PPW, "the last K tile of a chunk must not carry patch loads");
-  static_assert(LDS <= 160 * 1024 && LDS >= OUT_LDS, "LDS budget");
+  static_assert(LDS <= 160 * 1024 && BIAS_OFF >= OUT_LDS, "LDS budget (the staged epilogue must not reach the bias)");
 };
 
 struct IgemmHaloParams {
@@ -56,7 +57,63 @@ struct IgemmHaloParams {
   int wtoff[4][9];     // per class, per tap: byte offset of the tap's Cin weights inside a weight row
   int dymin[4], dxmin[4];
   int tps, tpr;        // m tiles per sample, per tile row
+  unsigned dv[5][3];   // exact unsigned division by ntiles, nclass, mtiles, tps, tpr: (multiplier, shift 1, shift 2)
 };
+
+// q = n / d for any 32-bit n with the host-made constants of d (Granlund-Montgomery): three scalar instructions instead
+// of the ~25 of a run-time division -- a tile's set-up does five of them before it can issue its first load
+__device__ __forceinline__ int fastdiv(int n, const unsigned (&c)[3]) {
+  const unsigned t = __umulhi((unsigned)n, c[0]);
+  return (int)((t + (((unsigned)n - t) >> c[1])) >> c[2]);
+}
+static void fastdiv_make(unsigned d, unsigned (&c)[3]) {
+  unsigned L = 0;
+  while ((1ull << L) < d) ++L;
+  c[0] = (unsigned)((((1ull << 32) * ((1ull << L) - d)) / d) + 1);
+  c[1] = L < 1 ? L : 1;
+  c[2] = L < 1 ? 0 : L - 1;
+}
+
+// tile decode shared by the two kernels.  Every kernel-argument field the set-up needs is fetched in ONE batch up front
+// (the empty asm pins the values there): left to itself the compiler loads each field right before its first use, which
+// made the set-up a chain of seven dependent scalar-load round trips (2 K tiles' worth of time per tile, stamp build).
+struct HaloTile { int nt, mt, cls, b, ty0, tx0; };
+__device__ __forceinline__ HaloTile halo_tile(const IgemmHaloParams &P) {
+  const IgemmParams &p = P.g;
+  const int nblocks = p.nblocks, ntiles = p.ntiles, nclass = p.nclass, mtiles = p.mtiles, cls_fast = P.cls_fast;
+  const int tps = P.tps, tpr = P.tpr;
+  unsigned dv[5][3];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dv[i][j] = P.dv[i][j];
+  {   // (used by the caller right after: buffer descriptors, patch and weight addresses)
+    const char *x = p.x, *w = p.w;
+    const unsigned xb = P.xbytes, wb = P.wbytes;
+    const int Hi = p.Hi, Wi = p.Wi, ldx = p.ldx, Kw = p.Kw, cpt = p.cpt;
+    asm volatile("" ::"s"(x), "s"(w), "s"(xb), "s"(wb), "s"(Hi), "s"(Wi), "s"(ldx), "s"(Kw), "s"(cpt));
+  }
+  asm volatile("" ::"s"(nblocks), "s"(ntiles), "s"(nclass), "s"(mtiles), "s"(cls_fast), "s"(tps), "s"(tpr), "s"(dv[0][0]),
+               "s"(dv[0][1]), "s"(dv[0][2]), "s"(dv[1][0]), "s"(dv[1][1]), "s"(dv[1][2]), "s"(dv[2][0]), "s"(dv[2][1]),
+               "s"(dv[2][2]), "s"(dv[3][0]), "s"(dv[3][1]), "s"(dv[3][2]), "s"(dv[4][0]), "s"(dv[4][1]), "s"(dv[4][2]));
+  // XCD-aware block remap (bijective), as in igemm256_kernel
+  int bid = blockIdx.x;
+  {
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  HaloTile t;
+  int q = fastdiv(bid, dv[0]);
+  t.nt = bid - q * ntiles; bid = q;
+  if (cls_fast) { q = fastdiv(bid, dv[1]); t.cls = bid - q * nclass; t.mt = q; }
+  else { q = fastdiv(bid, dv[2]); t.mt = bid - q * mtiles; t.cls = q; }
+  t.b = fastdiv(t.mt, dv[3]);
+  const int trem = t.mt - t.b * tps;
+  const int tyi = fastdiv(trem, dv[4]);
+  t.ty0 = tyi * 8;
+  t.tx0 = (trem - tyi * tpr) * 32;
+  return t;
+}
 
 template <int N> __device__ __forceinline__ void hwait() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -83,22 +140,10 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
   const bool act_any = p.act == CFD_ACT_LEAKY || p.act == CFD_ACT_RELU;   // (uniform)
   const bool act_sig = p.act == CFD_ACT_SIGMOID;
 
-  // ---- XCD-aware block remap (bijective), as in igemm256_kernel
-  int bid = blockIdx.x;
-  {
-    const int nwg = p.nblocks, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int nt = bid % p.ntiles; bid /= p.ntiles;
-  int mt, cls;
-  if (P.cls_fast) { cls = bid % p.nclass; bid /= p.nclass; mt = bid; }
-  else { mt = bid % p.mtiles; bid /= p.mtiles; cls = bid; }
-  const int ph = cls >> 1, pw = cls & 1;
-  const int n0 = nt * 256;
-  const int b = mt / P.tps;
-  const int trem = mt - b * P.tps;
-  const int tyi = trem / P.tpr;
-  const int ty0 = tyi * H_TH, tx0 = (trem - tyi * P.tpr) * H_TW;
+  const HaloTile tile = halo_tile(P);
+  const int cls = tile.cls, ph = cls >> 1, pw = cls & 1;
+  const int n0 = tile.nt * 256;
+  const int b = tile.b, ty0 = tile.ty0, tx0 = tile.tx0;
   const int cpt = p.cpt;
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)P.xbytes, 0x00020000);
@@ -162,6 +207,13 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: patch of chunk 0, A0(0), A1(0), A0(1)
+  // the bias of this n tile goes to LDS with the very first load (every wave issues the same 1 KiB, so the vmcnt
+  // bookkeeping stays uniform; it is the oldest load and retires with the first wait): fetched from global memory in
+  // the epilogue it cost a full round trip per tile (~1 us: P d5 447 -> 463 us, DeltaP g3 203 -> 221 with a bias)
+  if (p.bias) {
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, p.Cout * 4, 0x00020000);
+    bload16(brs, (unsigned)(n0 * 4 + lane * 16), 0u, lds + G::BIAS_OFF);
+  }
 #pragma unroll
   for (int j = 0; j < G::PPW; ++j) issueP(j, 0, 0u);
   issueA0(0, (unsigned)wto[0]);
@@ -253,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
     for (int i = 0; i < 8; ++i) {
       const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+      if (p.bias) bv = *(const f32x4 *)(lds + G::BIAS_OFF + nl * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float t1 = 0.f, t2 = 0.f;
@@ -290,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
     for (int i = 0; i < 8; ++i) {
       const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+      if (p.bias) bv = *(const f32x4 *)(lds + G::BIAS_OFF + nl * 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int local = (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fr;
@@ -334,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
       for (int i = 0; i < 8; ++i) {
         const int nl = (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+        if (p.bias) bv = *(const f32x4 *)(lds + G::BIAS_OFF + nl * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           f32x4 v = acc[i][j] + bv;
@@ -367,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
         for (int i = 0; i < 8; ++i) {
           const int n = n0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fq * 4;
           f32x4 v = acc[i][j];
-          if (p.bias) v += *(const f32x4 *)(p.bias + n);
+          if (p.bias) v += *(const f32x4 *)(lds + G::BIAS_OFF + (n - n0) * 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);   // ns = 1: identity
           if (act_sig) {
@@ -400,7 +452,8 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
 constexpr int H3_ABYTES = 3 * HT_BYTES;
 
 template <int NT> struct HaloGeo3 : HaloGeo<NT> {
-  static constexpr int LDS = H3_ABYTES + 2 * HaloGeo<NT>::PATCH;
+  static constexpr int BIAS_OFF = H3_ABYTES + 2 * HaloGeo<NT>::PATCH;
+  static constexpr int LDS = BIAS_OFF + 1024;
 };
 
 template <int N> __device__ __forceinline__ void hwait3() {
@@ -424,21 +477,10 @@ __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
   const float act_ns = act_neg_scale(p.act, p.slope);
   const bool act_sig = p.act == CFD_ACT_SIGMOID;
 
-  int bid = blockIdx.x;
-  {
-    const int nwg = p.nblocks, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int nt = bid % p.ntiles; bid /= p.ntiles;
-  int mt, cls;
-  if (P.cls_fast) { cls = bid % p.nclass; bid /= p.nclass; mt = bid; }
-  else { mt = bid % p.mtiles; bid /= p.mtiles; cls = bid; }
-  const int ph = cls >> 1, pw = cls & 1;
-  const int n0 = nt * 128;
-  const int b = mt / P.tps;
-  const int trem = mt - b * P.tps;
-  const int tyi = trem / P.tpr;
-  const int ty0 = tyi * H_TH, tx0 = (trem - tyi * P.tpr) * H_TW;
+  const HaloTile tile = halo_tile(P);
+  const int cls = tile.cls, ph = cls >> 1, pw = cls & 1;
+  const int n0 = tile.nt * 128;
+  const int b = tile.b, ty0 = tile.ty0, tx0 = tile.tx0;
   const int cpt = p.cpt;
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)P.xbytes, 0x00020000);
@@ -493,6 +535,13 @@ __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // the bias of this n tile goes to LDS with the very first load (every wave issues the same 1 KiB, so the vmcnt
+  // bookkeeping stays uniform; it is the oldest load and retires with the first wait): fetched from global memory in
+  // the epilogue it cost a full round trip per tile (~1 us: P d5 447 -> 463 us, DeltaP g3 203 -> 221 with a bias)
+  if (p.bias) {
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, p.Cout * 4, 0x00020000);
+    bload16(brs, (unsigned)(n0 * 4 + lane * 16), 0u, lds + G::BIAS_OFF);
+  }
 #pragma unroll
   for (int j = 0; j < G::PPW; ++j) issueP(j, 0, 0u);
   issueA(0, (unsigned)wto[0]);
@@ -570,7 +619,7 @@ __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
     for (int i = 0; i < 4; ++i) {
       const int nl = wr * 64 + i * 16 + fq * 4;
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
+      if (p.bias) bv = *(const f32x4 *)(lds + G::BIAS_OFF + nl * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float t1 = 0.f, t2 = 0.f;
@@ -606,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
       for (int i = 0; i < 4; ++i) {
         const int n = n0 + wr * 64 + i * 16 + fq * 4;
         f32x4 v = acc[i][j];
-        if (p.bias) v += *(const f32x4 *)(p.bias + n);
+        if (p.bias) v += *(const f32x4 *)(lds + G::BIAS_OFF + (n - n0) * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);
         if (act_sig) {
@@ -645,6 +694,8 @@ int igemm256h_launch(const IgemmParams &pin, int ntile, unsigned xbytes, unsigne
   P.xbytes = xbytes; P.wbytes = wbytes; P.cls_fast = cls_fast; P.stage_out = stage_out;
   P.tpr = p.Wq / H_TW;
   P.tps = (p.Hq / H_TH) * P.tpr;
+  fastdiv_make((unsigned)p.ntiles, P.dv[0]); fastdiv_make((unsigned)p.nclass, P.dv[1]); fastdiv_make((unsigned)p.mtiles, P.dv[2]);
+  fastdiv_make((unsigned)P.tps, P.dv[3]); fastdiv_make((unsigned)P.tpr, P.dv[4]);
   CFD_REQUIRE((int64_t)P.tps * p.B == p.mtiles && (int64_t)p.mtiles * p.ntiles * p.nclass == p.nblocks,
               "patch-staged kernel: tile count %d does not match the 8 x 32 tiling", p.mtiles);
   const int ph_rows = H_TH + (p.ntaps == 9 ? 2 : 1);

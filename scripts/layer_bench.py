@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--staged-out", type=int, default=-1, help="-1/1 staged bf16 epilogue where legal, 0 off")
     ap.add_argument("--ntile", type=int, default=-1, help="-1 heuristic, 128 / 256: n tile of the ping-pong kernels")
     ap.add_argument("--only", default="", help="comma list of layer names, e.g. e2,d4")
+    ap.add_argument("--bias", type=int, default=0, help="1: forward launches add a bias vector (as the nets do)")
     args = ap.parse_args()
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     ops.set_tuning(ops.TUNE_IGEMM256, args.igemm256)
@@ -106,7 +107,8 @@ def main():
             flops = 2.0 * opix * cout * TAPS[kind] * cin
             bk = {CONV_K4S2: CONVT_K4S2, CONVT_K4S2: CONV_K4S2, CONV_K3S1: CONV_K3S1, DENSE: DENSE,
                   CONV_K4S1: CONV_K4S1_BWD}[kind]
-            fns = {"fwd": lambda: ops.conv_forward(x, wt, None, kind, cout, out=y),
+            bias = torch.zeros(cout, device="cuda") if args.bias else None
+            fns = {"fwd": lambda: ops.conv_forward(x, wt, bias, kind, cout, out=y),
                    "dgrad": lambda: ops.conv_forward(dy, wtt, None, bk, cin, out=dx),
                    "wgrad": lambda: ops.conv_wgrad(x, dy, kind, cout, dw)}
             for m in modes:
