@@ -19,6 +19,7 @@ struct Igemm256Params {
   int tgeo[4][8];            // per class: kw, kh, dy0, dys, dx0, dxs -- the taps form a kh x kw grid, tap t = ky*kw + kx
                              // sits at (dy0 + dys*ky, dx0 + dxs*kx)
   int stage_out;             // bf16 output tile goes through LDS and leaves as whole 512-B pixel rows
+  unsigned dv[3][3];         // fastdiv constants of ntiles, nclass, mtiles (block index -> tile)
 };
 
 // LDS-staged output (bf16, no split-K): measured with the stamp build, the direct epilogue -- 32 stores per lane, each
@@ -41,6 +42,20 @@ __device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
   return c;
+}
+
+// q = n / d for any 32-bit n with the host-made constants of d (Granlund-Montgomery): three scalar instructions instead
+// of the ~25 of a run-time division -- a tile's set-up does five of them before it can issue its first load
+__device__ __forceinline__ int fastdiv(int n, const unsigned (&c)[3]) {
+  const unsigned t = __umulhi((unsigned)n, c[0]);
+  return (int)((t + (((unsigned)n - t) >> c[1])) >> c[2]);
+}
+static void fastdiv_make(unsigned d, unsigned (&c)[3]) {
+  unsigned L = 0;
+  while ((1ull << L) < d) ++L;
+  c[0] = (unsigned)((((1ull << 32) * ((1ull << L) - d)) / d) + 1);
+  c[1] = L < 1 ? L : 1;
+  c[2] = L < 1 ? 0 : L - 1;
 }
 
 // igemm256h.hip: patch-staged variant (bf16, 3x3 stride 1 and the transposed 4x4 stride 2, no split-K).  `p` as prepared

@@ -79,6 +79,31 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
+// The kernel-argument fields a tile's set-up needs, fetched in ONE batch (the empty asm pins the values there): left to itself
+// the compiler loads each field right before its first use, which made the set-up a chain of ~nine dependent scalar-load
+// round trips; the block-index decode divides by host-made constants (fastdiv) instead of five run-time divisions.
+#define CFD_KARGS_BATCH(P)                                                                                            \
+  const int k_nblocks = (P).g.nblocks, k_ntiles = (P).g.ntiles, k_nclass = (P).g.nclass, k_mtiles = (P).g.mtiles,     \
+            k_cls_fast = (P).cls_fast;                                                                                \
+  unsigned kdv[3][3];                                                                                                 \
+  _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                                                    \
+    _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_) kdv[i_][j_] = (P).dv[i_][j_];                                    \
+  {                                                                                                                   \
+    const char *x_ = (P).g.x, *w_ = (P).g.w;                                                                          \
+    const unsigned xb_ = (P).xbytes, wb_ = (P).wbytes;                                                                \
+    const int a_ = (P).g.Hi, b_ = (P).g.Wi, c_ = (P).g.ldx, d_ = (P).g.Kw, e_ = (P).g.cpt, f_ = (P).g.ntaps,          \
+              g_ = (P).g.split_k, h_ = (P).g.M, i2_ = (P).g.hw_shift, j2_ = (P).g.wq_shift, k_ = (P).g.kind,          \
+              l_ = (P).g.pool, m_ = (P).g.Cin, n_ = (P).g.Hq, o_ = (P).g.Wq, p_ = (P).g.Ho, q_ = (P).g.Wo,            \
+              r_ = (P).g.Cout;                                                                                        \
+    const float *bias_ = (P).g.bias;                                                                                  \
+    asm volatile("" ::"s"(x_), "s"(w_), "s"(xb_), "s"(wb_), "s"(a_), "s"(b_), "s"(c_), "s"(d_), "s"(e_), "s"(f_),     \
+                 "s"(g_), "s"(h_), "s"(i2_), "s"(j2_), "s"(k_), "s"(l_), "s"(m_), "s"(n_), "s"(o_), "s"(p_), "s"(q_), \
+                 "s"(r_), "s"(bias_));                                                                                         \
+  }                                                                                                                   \
+  asm volatile("" ::"s"(k_nblocks), "s"(k_ntiles), "s"(k_nclass), "s"(k_mtiles), "s"(k_cls_fast), "s"(kdv[0][0]),    \
+               "s"(kdv[0][1]), "s"(kdv[0][2]), "s"(kdv[1][0]), "s"(kdv[1][1]), "s"(kdv[1][2]), "s"(kdv[2][0]),        \
+               "s"(kdv[2][1]), "s"(kdv[2][2]));
+
 // T = bf16: K tile = 64 elements, mfma_f32_16x16x32_bf16.  T = float: K tile = 32 elements, exact-f32
 // mfma_f32_16x16x4f32; a 16-B fragment read then feeds four MFMAs (lane group fq supplies k = 16 s + 4 fq + e
 // on BOTH operands -- any consistent k assignment sums to the same dot product).  Rows are 128 B either way.
@@ -109,16 +134,29 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   CFD_TSTAMP(0)
 
   // ---- XCD-aware block remap (bijective)
+  CFD_KARGS_BATCH(P)
   int bid = blockIdx.x;
   {
-    const int nwg = p.nblocks, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int nwg = k_nblocks, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int nt = bid % p.ntiles; bid /= p.ntiles;
-  int mt, cls;
-  if (P.cls_fast) { cls = bid % p.nclass; bid /= p.nclass; mt = bid % p.mtiles; bid /= p.mtiles; }
-  else { mt = bid % p.mtiles; bid /= p.mtiles; cls = bid % p.nclass; bid /= p.nclass; }
+  int nt, mt, cls;
+  {
+    int q = fastdiv(bid, kdv[0]);
+    nt = bid - q * k_ntiles; bid = q;
+    if (k_cls_fast) {
+      q = fastdiv(bid, kdv[1]); cls = bid - q * k_nclass; bid = q;
+      q = fastdiv(bid, kdv[2]); mt = bid - q * k_mtiles; bid = q;
+    } else {
+      q = fastdiv(bid, kdv[2]); mt = bid - q * k_mtiles; bid = q;
+      q = fastdiv(bid, kdv[1]); cls = bid - q * k_nclass; bid = q;
+    }
+  }
   const int sk = bid;
+  int tg8[8];   // this class's tap grid, one batch (tap_mask and the tap walk read it)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) tg8[i] = P.tgeo[cls][i];
+  asm volatile("" ::"s"(tg8[0]), "s"(tg8[1]), "s"(tg8[2]), "s"(tg8[3]), "s"(tg8[4]), "s"(tg8[5]), "s"(tg8[6]), "s"(tg8[7]));
   const int ph = cls >> 1, pw = cls & 1;
   const int m0 = mt * 256, n0 = nt * 256;
   const int S = (p.kind == CFD_CONV_K4S2) ? 2 : 1;
@@ -153,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
     split_pixel(p, mm, b, qy, qx);
     const int y0 = qy * S, x0 = qx * S;
     rowoff[r] = (unsigned)((((b * p.Hi + y0) * p.Wi + x0) * p.ldx + chunk * EPC) * ES);
-    vmask[r] = tap_mask(P.tgeo[cls], y0, x0, p.Hi, p.Wi, mv);
+    vmask[r] = tap_mask(tg8, y0, x0, p.Hi, p.Wi, mv);
   }
 
   // ---- issue stream state (uniform): the K tile whose half tiles are being issued
@@ -166,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void igemm256_kernel(Igemm256Params P) {
   // taps of every kind form an affine grid (checked by the host), so the walk is a handful of scalar adds instead:
   // tw_pix = (dy*Wi + dx) of the current tap, tw_wt = its weight tap index, (tw_kx) its column in the kh x kw grid.
   TapWalk tw;
-  tw.init(P.tgeo[cls], p.Wi, iss_t);
+  tw.init(tg8, p.Wi, iss_t);
   auto tap_switch = [&]() {
     s_a = (unsigned)((tw.wt * p.Cin + iss_c * BKE) * ES);
     s_b = (unsigned)(iss_c * 128);
@@ -882,16 +920,29 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
   const bool act_any = p.act == CFD_ACT_LEAKY || p.act == CFD_ACT_RELU;   // (uniform)
   const bool act_sig = p.act == CFD_ACT_SIGMOID;   // (uniform; never set by the nets for these kernels)
 
+  CFD_KARGS_BATCH(P)
   int bid = blockIdx.x;
   {
-    const int nwg = p.nblocks, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int nwg = k_nblocks, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int nt = bid % p.ntiles; bid /= p.ntiles;
-  int mt, cls;
-  if (P.cls_fast) { cls = bid % p.nclass; bid /= p.nclass; mt = bid % p.mtiles; bid /= p.mtiles; }
-  else { mt = bid % p.mtiles; bid /= p.mtiles; cls = bid % p.nclass; bid /= p.nclass; }
+  int nt, mt, cls;
+  {
+    int q = fastdiv(bid, kdv[0]);
+    nt = bid - q * k_ntiles; bid = q;
+    if (k_cls_fast) {
+      q = fastdiv(bid, kdv[1]); cls = bid - q * k_nclass; bid = q;
+      q = fastdiv(bid, kdv[2]); mt = bid - q * k_mtiles; bid = q;
+    } else {
+      q = fastdiv(bid, kdv[2]); mt = bid - q * k_mtiles; bid = q;
+      q = fastdiv(bid, kdv[1]); cls = bid - q * k_nclass; bid = q;
+    }
+  }
   const int sk = bid;
+  int tg8[8];   // this class's tap grid, one batch (tap_mask and the tap walk read it)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) tg8[i] = P.tgeo[cls][i];
+  asm volatile("" ::"s"(tg8[0]), "s"(tg8[1]), "s"(tg8[2]), "s"(tg8[3]), "s"(tg8[4]), "s"(tg8[5]), "s"(tg8[6]), "s"(tg8[7]));
   const int ph = cls >> 1, pw = cls & 1;
   const int m0 = mt * 256, n0 = nt * 128;
   const int S = (p.kind == CFD_CONV_K4S2) ? 2 : 1;
@@ -920,7 +971,7 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
     split_pixel(p, mm, b, qy, qx);
     const int y0 = qy * S, x0 = qx * S;
     rowoff[r] = (unsigned)((((b * p.Hi + y0) * p.Wi + x0) * p.ldx + chunk * EPC) * ES);
-    vmask[r] = tap_mask(P.tgeo[cls], y0, x0, p.Hi, p.Wi, mv);
+    vmask[r] = tap_mask(tg8, y0, x0, p.Hi, p.Wi, mv);
   }
 
   int iss_left = nkt;
@@ -932,7 +983,7 @@ __global__ __launch_bounds__(512, 2) void igemm128n_kernel(Igemm256Params P) {
   // taps of every kind form an affine grid (checked by the host), so the walk is a handful of scalar adds instead:
   // tw_pix = (dy*Wi + dx) of the current tap, tw_wt = its weight tap index, (tw_kx) its column in the kh x kw grid.
   TapWalk tw;
-  tw.init(P.tgeo[cls], p.Wi, iss_t);
+  tw.init(tg8, p.Wi, iss_t);
   auto tap_switch = [&]() {
     s_a = (unsigned)((tw.wt * p.Cin + iss_c * BKE) * ES);
     s_b = (unsigned)(iss_c * 128);
@@ -1143,6 +1194,7 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   // and share the input rows in its L2) when the activations outweigh the weights, else class-major (each class
   // streams only its own quarter of the weights)
   const int co = tuning(CFD_TUNE_CLASS_ORDER);
+  fastdiv_make((unsigned)p.ntiles, P.dv[0]); fastdiv_make((unsigned)p.nclass, P.dv[1]); fastdiv_make((unsigned)p.mtiles, P.dv[2]);
   P.cls_fast = p.nclass > 1 && (co < 0 ? x_bytes(p, es) > w_bytes(p, es) : co == 1);
   for (int cls = 0; cls < p.nclass; ++cls)
     for (int t = 0; t < p.ntaps; ++t) {

@@ -60,20 +60,6 @@ struct IgemmHaloParams {
   unsigned dv[5][3];   // exact unsigned division by ntiles, nclass, mtiles, tps, tpr: (multiplier, shift 1, shift 2)
 };
 
-// q = n / d for any 32-bit n with the host-made constants of d (Granlund-Montgomery): three scalar instructions instead
-// of the ~25 of a run-time division -- a tile's set-up does five of them before it can issue its first load
-__device__ __forceinline__ int fastdiv(int n, const unsigned (&c)[3]) {
-  const unsigned t = __umulhi((unsigned)n, c[0]);
-  return (int)((t + (((unsigned)n - t) >> c[1])) >> c[2]);
-}
-static void fastdiv_make(unsigned d, unsigned (&c)[3]) {
-  unsigned L = 0;
-  while ((1ull << L) < d) ++L;
-  c[0] = (unsigned)((((1ull << 32) * ((1ull << L) - d)) / d) + 1);
-  c[1] = L < 1 ? L : 1;
-  c[2] = L < 1 ? 0 : L - 1;
-}
-
 // tile decode shared by the two kernels.  Every kernel-argument field the set-up needs is fetched in ONE batch up front
 // (the empty asm pins the values there): left to itself the compiler loads each field right before its first use, which
 // made the set-up a chain of seven dependent scalar-load round trips (2 K tiles' worth of time per tile, stamp build).
