@@ -34,8 +34,8 @@ constexpr int H_TH = 8, H_TW = 32, H_PW = 34;
 constexpr int H_ABYTES = 4 * HT_BYTES;   // two stages of (A0, A1)
 constexpr int H_BROW = 4 * H_PW * 128;   // byte distance between a wave's two tile rows (wc and 4 + wc) in the patch
 
-template <int NT> struct HaloGeo {
-  static constexpr int PH = H_TH + (NT == 9 ? 2 : 1);
+template <int NT, bool S2 = false> struct HaloGeo {
+  static constexpr int PH = H_TH + ((NT == 9 || S2) ? 2 : 1);
   static constexpr int PP = PH * H_PW;           // patch pixels
   static constexpr int NPI = (PP + 7) / 8;       // wave-level load instructions (8 pixels = 1 KiB each)
   static constexpr int PPW = (NPI + 7) / 8;      // ... per wave
@@ -111,10 +111,31 @@ template <int N> __device__ __forceinline__ void hwait() {
 
 template <int V> using IC = std::integral_constant<int, V>;
 
-template <int NT>
+// The chunk walk.  A chunk = 64 input channels of one GROUP; 3x3 and transposed layers have one group.  A 4x4 stride-2
+// convolution (S2) is four 2x2-tap stride-1 convolutions over the four input parities (r, s) -- input pixel (2y + r, 2x + s)
+// of the space-to-depth grid (y, x) -- all accumulating into the same output tile: four groups, each with the patch
+// geometry of the 3x3 kernel (origin (ty0 - 1, tx0 - 1), 10 x 34 pixels).  Tap (ty, tx) of group (r, s) reads the grid at
+// (y + ty - r, x + tx - s) and the weights of kernel position (2 ty + 1 - r, 2 tx + 1 - s): the tables hold the r = s = 0
+// values, the group shifts them by a constant.
+struct HaloChunk {
+  int a;   // byte offset inside a weight row: group shift + chunk * 128
+  int t;   // patch-pixel shift of the group's taps
+  int p;   // scalar byte offset of the chunk's patch source: parity pixel + chunk * 128
+};
+template <bool S2>
+__device__ __forceinline__ HaloChunk halo_chunk(int g, int c, int cin2, int wi, int ldx2) {
+  if constexpr (S2) {
+    const int r = g >> 1, s = g & 1;
+    return {c * 128 - (r * 4 + s) * cin2, -(r * H_PW + s), (r * wi + s) * ldx2 + c * 128};
+  } else {
+    return {c * 128, 0, c * 128};
+  }
+}
+
+template <int NT, bool S2 = false>
 __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
-  using G = HaloGeo<NT>;
+  using G = HaloGeo<NT, S2>;
   const IgemmParams &p = P.g;
   typedef bf16x8 frag_t;
 
@@ -131,6 +152,16 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
   const int n0 = tile.nt * 256;
   const int b = tile.b, ty0 = tile.ty0, tx0 = tile.tx0;
   const int cpt = p.cpt;
+  const int ncc = S2 ? 4 * cpt : cpt;                       // chunks of the whole K range
+  const int cin2 = p.Cin * 2, ldx2 = p.ldx * 2;
+  int ng = 0, nc = 0;                                       // group / chunk-in-group of `nxt`
+  auto chunk_step = [&]() {                                 // (clamped at the last chunk: the stream's overrun re-reads it)
+    if (nc + 1 < cpt) ++nc;
+    else if (S2 && ng < 3) { nc = 0; ++ng; }
+  };
+  HaloChunk cur = halo_chunk<S2>(0, 0, cin2, p.Wi, ldx2);
+  chunk_step();
+  HaloChunk nxt = halo_chunk<S2>(ng, nc, cin2, p.Wi, ldx2);
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)P.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)P.wbytes, 0x00020000);
@@ -159,8 +190,9 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
       const int pp = q * 8 + lrow;
       const int py = pp / H_PW, px = pp - py * H_PW;
       const int y = py0 + py, x = px0 + px;
-      const bool ok = pp < G::PP && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
-      pvoff[j] = ok ? (unsigned)((((b * p.Hi + y) * p.Wi + x) * p.ldx + chunk * 8) * 2) : OOB;
+      constexpr int S = S2 ? 2 : 1;   // (y, x) is on the class grid; S2: the space-to-depth grid of the input
+      const bool ok = pp < G::PP && (unsigned)y < (unsigned)p.Hq && (unsigned)x < (unsigned)p.Wq;
+      pvoff[j] = ok ? (unsigned)((((b * p.Hi + S * y) * p.Wi + S * x) * p.ldx + chunk * 8) * 2) : OOB;
     }
   }
 
@@ -201,10 +233,10 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
     bload16(brs, (unsigned)(n0 * 4 + lane * 16), 0u, lds + G::BIAS_OFF);
   }
 #pragma unroll
-  for (int j = 0; j < G::PPW; ++j) issueP(j, 0, 0u);
-  issueA0(0, (unsigned)wto[0]);
-  issueA1(0, (unsigned)wto[0]);
-  issueA0(1, (unsigned)(wto[1 % NT] + min(1 / NT, cpt - 1) * 128));
+  for (int j = 0; j < G::PPW; ++j) issueP(j, 0, (unsigned)cur.p);
+  issueA0(0, (unsigned)(wto[0] + cur.a));
+  issueA1(0, (unsigned)(wto[0] + cur.a));
+  issueA0(1, (unsigned)(wto[1 % NT] + (1 / NT ? nxt.a : cur.a)));
   hwait<4>();
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // second group runs one barrier behind
@@ -233,12 +265,12 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
     constexpr int t1 = (t + 1) % NT, k1 = (t + 1) / NT, t2 = (t + 2) % NT, k2 = (t + 2) / NT;
     const int st = (NT & 1) ? ((c + t) & 1) : (t & 1);
     const int pst = c & 1;
-    const unsigned sa1 = (unsigned)(wto[t1] + min(c + k1, cpt - 1) * 128);
-    const unsigned sa2 = (unsigned)(wto[t2] + min(c + k2, cpt - 1) * 128);
-    const unsigned sp = (unsigned)(min(c + 1, cpt - 1) * 128);
+    const unsigned sa1 = (unsigned)(wto[t1] + (k1 ? nxt.a : cur.a));
+    const unsigned sa2 = (unsigned)(wto[t2] + (k2 ? nxt.a : cur.a));
+    const unsigned sp = (unsigned)nxt.p;
     const int stoff = st * (2 * HT_BYTES);
     {   // phase A: A0 x (B rows wc | 4 + wc)
-      const int pp = L0 + toff[t];
+      const int pp = L0 + toff[t] + cur.t;
       const int bo = H_ABYTES + pst * G::PATCH + (pp << 7) + ((fq ^ (pp & 7)) << 4);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -265,11 +297,14 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
     }
   };
 
-  for (int c = 0; c < cpt; ++c) {
+  for (int c = 0; c < ncc; ++c) {
     ktile(IC<0>{}, c); ktile(IC<1>{}, c); ktile(IC<2>{}, c); ktile(IC<3>{}, c);
     if constexpr (NT == 9) {
       ktile(IC<4>{}, c); ktile(IC<5>{}, c); ktile(IC<6>{}, c); ktile(IC<7>{}, c); ktile(IC<8>{}, c);
     }
+    cur = nxt;
+    chunk_step();
+    nxt = halo_chunk<S2>(ng, nc, cin2, p.Wi, ldx2);
   }
 #undef CFD_SYNC_MFMA
 #undef CFD_MFMA
@@ -437,8 +472,8 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int H3_ABYTES = 3 * HT_BYTES;
 
-template <int NT> struct HaloGeo3 : HaloGeo<NT> {
-  static constexpr int BIAS_OFF = H3_ABYTES + 2 * HaloGeo<NT>::PATCH;
+template <int NT, bool S2 = false> struct HaloGeo3 : HaloGeo<NT, S2> {
+  static constexpr int BIAS_OFF = H3_ABYTES + 2 * HaloGeo<NT, S2>::PATCH;
   static constexpr int LDS = BIAS_OFF + 1024;
 };
 
@@ -449,10 +484,10 @@ template <int N> __device__ __forceinline__ void hwait3() {
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
-template <int NT>
+template <int NT, bool S2 = false>
 __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
-  using G = HaloGeo3<NT>;
+  using G = HaloGeo3<NT, S2>;
   const IgemmParams &p = P.g;
   typedef bf16x8 frag_t;
 
@@ -468,6 +503,16 @@ __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
   const int n0 = tile.nt * 128;
   const int b = tile.b, ty0 = tile.ty0, tx0 = tile.tx0;
   const int cpt = p.cpt;
+  const int ncc = S2 ? 4 * cpt : cpt;                       // chunks of the whole K range
+  const int cin2 = p.Cin * 2, ldx2 = p.ldx * 2;
+  int ng = 0, nc = 0;                                       // group / chunk-in-group of `nxt`
+  auto chunk_step = [&]() {                                 // (clamped at the last chunk: the stream's overrun re-reads it)
+    if (nc + 1 < cpt) ++nc;
+    else if (S2 && ng < 3) { nc = 0; ++ng; }
+  };
+  HaloChunk cur = halo_chunk<S2>(0, 0, cin2, p.Wi, ldx2);
+  chunk_step();
+  HaloChunk nxt = halo_chunk<S2>(ng, nc, cin2, p.Wi, ldx2);
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)P.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)P.wbytes, 0x00020000);
@@ -493,8 +538,9 @@ __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
       const int pp = q * 8 + lrow;
       const int py = pp / H_PW, px = pp - py * H_PW;
       const int y = py0 + py, x = px0 + px;
-      const bool ok = pp < G::PP && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
-      pvoff[j] = ok ? (unsigned)((((b * p.Hi + y) * p.Wi + x) * p.ldx + chunk * 8) * 2) : OOB;
+      constexpr int S = S2 ? 2 : 1;   // (y, x) is on the class grid; S2: the space-to-depth grid of the input
+      const bool ok = pp < G::PP && (unsigned)y < (unsigned)p.Hq && (unsigned)x < (unsigned)p.Wq;
+      pvoff[j] = ok ? (unsigned)((((b * p.Hi + S * y) * p.Wi + S * x) * p.ldx + chunk * 8) * 2) : OOB;
     }
   }
 
@@ -529,9 +575,9 @@ __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
     bload16(brs, (unsigned)(n0 * 4 + lane * 16), 0u, lds + G::BIAS_OFF);
   }
 #pragma unroll
-  for (int j = 0; j < G::PPW; ++j) issueP(j, 0, 0u);
-  issueA(0, (unsigned)wto[0]);
-  issueA(1, (unsigned)(wto[1 % NT] + min(1 / NT, cpt - 1) * 128));
+  for (int j = 0; j < G::PPW; ++j) issueP(j, 0, (unsigned)cur.p);
+  issueA(0, (unsigned)(wto[0] + cur.a));
+  issueA(1, (unsigned)(wto[1 % NT] + (1 / NT ? nxt.a : cur.a)));
   hwait3<2>();
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();
@@ -547,9 +593,9 @@ __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
     if constexpr (NT % 3 == 0) st = t % 3; else st = stg;
     const int st2 = st == 0 ? 2 : st - 1;   // (st + 2) % 3
     const int pst = c & 1;
-    const unsigned sa2 = (unsigned)(wto[t2] + min(c + k2, cpt - 1) * 128);
-    const unsigned sp = (unsigned)(min(c + 1, cpt - 1) * 128);
-    const int pp0 = L0 + toff[t], pp1 = pp0 + H_PW;
+    const unsigned sa2 = (unsigned)(wto[t2] + (k2 ? nxt.a : cur.a));
+    const unsigned sp = (unsigned)nxt.p;
+    const int pp0 = L0 + toff[t] + cur.t, pp1 = pp0 + H_PW;
     const int pb = H3_ABYTES + pst * G::PATCH;
     const int bo0 = pb + (pp0 << 7) + ((fq ^ (pp0 & 7)) << 4);
     const int bo1 = pb + (pp1 << 7) + ((fq ^ (pp1 & 7)) << 4);
@@ -583,11 +629,14 @@ __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
     if constexpr (NT % 3 != 0) stg = stg == 2 ? 0 : stg + 1;
   };
 
-  for (int c = 0; c < cpt; ++c) {
+  for (int c = 0; c < ncc; ++c) {
     ktile(IC<0>{}, c); ktile(IC<1>{}, c); ktile(IC<2>{}, c); ktile(IC<3>{}, c);
     if constexpr (NT == 9) {
       ktile(IC<4>{}, c); ktile(IC<5>{}, c); ktile(IC<6>{}, c); ktile(IC<7>{}, c); ktile(IC<8>{}, c);
     }
+    cur = nxt;
+    chunk_step();
+    nxt = halo_chunk<S2>(ng, nc, cin2, p.Wi, ldx2);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   hwait<0>();
@@ -664,9 +713,10 @@ __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
 // 4x4 stride-2 conv), whole 256-channel n tiles, no split-K, a class grid that 8 x 32 tiles cover exactly
 bool igemm256h_eligible(const IgemmParams &p, int dtype, int ntile) {
   if (tuning(CFD_TUNE_PATCH) == 0) return false;
-  return dtype == CFD_BF16 && (p.kind == CFD_CONV_K3S1 || p.kind == CFD_CONVT_K4S2) && p.Cout % ntile == 0 &&
-         p.Cin % 64 == 0 && p.split_k == 1 && (!p.pool || (ntile == 256 && p.nclass == 1 && p.out_bf16)) && p.Hq % H_TH == 0 && p.Wq % H_TW == 0 && p.Hi == p.Hq &&
-         p.Wi == p.Wq;
+  const bool s1 = (p.kind == CFD_CONV_K3S1 || p.kind == CFD_CONVT_K4S2) && p.Hi == p.Hq && p.Wi == p.Wq;
+  const bool s2 = p.kind == CFD_CONV_K4S2 && p.Hi == 2 * p.Hq && p.Wi == 2 * p.Wq && !p.pool;   // four parity groups
+  return dtype == CFD_BF16 && (s1 || s2) && p.Cout % ntile == 0 && p.Cin % 64 == 0 && p.split_k == 1 &&
+         (!p.pool || (ntile == 256 && p.nclass == 1 && p.out_bf16)) && p.Hq % H_TH == 0 && p.Wq % H_TW == 0;
 }
 
 int igemm256h_launch(const IgemmParams &pin, int ntile, unsigned xbytes, unsigned wbytes, int cls_fast, int stage_out,
@@ -684,9 +734,20 @@ int igemm256h_launch(const IgemmParams &pin, int ntile, unsigned xbytes, unsigne
   fastdiv_make((unsigned)P.tps, P.dv[3]); fastdiv_make((unsigned)P.tpr, P.dv[4]);
   CFD_REQUIRE((int64_t)P.tps * p.B == p.mtiles && (int64_t)p.mtiles * p.ntiles * p.nclass == p.nblocks,
               "patch-staged kernel: tile count %d does not match the 8 x 32 tiling", p.mtiles);
-  const int ph_rows = H_TH + (p.ntaps == 9 ? 2 : 1);
-  CFD_REQUIRE(p.ntaps == 9 || p.ntaps == 4, "patch-staged kernel: %d taps", p.ntaps);
-  for (int cls = 0; cls < p.nclass; ++cls) {
+  const bool s2 = p.kind == CFD_CONV_K4S2;
+  const int ph_rows = H_TH + ((p.ntaps == 9 || s2) ? 2 : 1);
+  CFD_REQUIRE(p.ntaps == 9 || p.ntaps == 4 || (s2 && p.ntaps == 16 && p.nclass == 1), "patch-staged kernel: %d taps", p.ntaps);
+  if (s2) {
+    // parity group (0, 0): tap (ty, tx) reads the space-to-depth grid at (y + ty, x + tx) = patch pixel (ty + 1, tx + 1) and
+    // the weights of kernel position (2 ty + 1, 2 tx + 1); group (r, s) shifts both by a constant (halo_chunk)
+    P.dymin[0] = -1; P.dxmin[0] = -1;
+    for (int t = 0; t < 4; ++t) {
+      const int ty = t >> 1, tx = t & 1;
+      P.toff[0][t] = (ty + 1) * H_PW + tx + 1;
+      P.wtoff[0][t] = ((2 * ty + 1) * 4 + 2 * tx + 1) * p.Cin * 2;
+    }
+  }
+  for (int cls = 0; cls < (s2 ? 0 : p.nclass); ++cls) {
     int dy[9], dx[9], wt[9], dymin = 1 << 20, dxmin = 1 << 20;
     for (int t = 0; t < p.ntaps; ++t) {
       tap_geom(p.kind, cls >> 1, cls & 1, t, dy[t], dx[t], wt[t]);
@@ -709,10 +770,16 @@ int igemm256h_launch(const IgemmParams &pin, int ntile, unsigned xbytes, unsigne
     }                                                                                                               \
     hipLaunchKernelGGL(KERNEL, dim3(p.nblocks), dim3(512), GEO::LDS, st, P);                                        \
   } while (0)
+  typedef HaloGeo<4, true> GeoS2;
+  typedef HaloGeo3<4, true> Geo3S2;
   if (ntile == 256) {
-    if (p.ntaps == 9) CFD_LAUNCH_H(igemm256h_kernel<9>, HaloGeo<9>); else CFD_LAUNCH_H(igemm256h_kernel<4>, HaloGeo<4>);
+    if (s2) CFD_LAUNCH_H((igemm256h_kernel<4, true>), GeoS2);
+    else if (p.ntaps == 9) CFD_LAUNCH_H(igemm256h_kernel<9>, HaloGeo<9>);
+    else CFD_LAUNCH_H(igemm256h_kernel<4>, HaloGeo<4>);
   } else {
-    if (p.ntaps == 9) CFD_LAUNCH_H(igemm128nh_kernel<9>, HaloGeo3<9>); else CFD_LAUNCH_H(igemm128nh_kernel<4>, HaloGeo3<4>);
+    if (s2) CFD_LAUNCH_H((igemm128nh_kernel<4, true>), Geo3S2);
+    else if (p.ntaps == 9) CFD_LAUNCH_H(igemm128nh_kernel<9>, HaloGeo3<9>);
+    else CFD_LAUNCH_H(igemm128nh_kernel<4>, HaloGeo3<4>);
   }
 #undef CFD_LAUNCH_H
   CFD_LAUNCH_CHECK();

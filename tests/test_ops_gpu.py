@@ -158,11 +158,15 @@ def test_conv_forward_igemm256_persistent(kind, B, H, W, cin, cout, split_k, pd)
     ("convT", 2, 8, 64, 64, 512),       # one chunk, two n tiles
     ("k3s1", 2, 8, 32, 64, 128),        # Cout = 128: the 128(n) variant only (DeltaP g3's shape class)
     ("convT", 1, 8, 32, 192, 384),      # three 128-wide n tiles, three chunks (ring stage runs on across chunks)
+    ("k4s2", 2, 16, 64, 64, 256),       # stride 2 = four input-parity groups into one output tile; one chunk per group
+    ("k4s2", 1, 32, 128, 192, 256),     # three chunks per group, 2 x 2 tiles: every image border in its own tile
+    ("k4s2", 3, 16, 192, 128, 384),     # three tiles per row, three 128-wide n tiles
 ])
 @pytest.mark.parametrize("ntile", [256, 128])
 def test_conv_forward_patch_staged(kind, B, H, W, cin, cout, ntile):
     """igemm256h_kernel (activation operand staged once per channel chunk as an input patch; bf16 3x3 and transposed 4x4
-    on whole 8 x 32 tiles) against the oracle, against the per-tap kernel, and reading a channel slice of a wider input"""
+    and, as four input-parity groups, 4x4 stride 2, on whole 8 x 32 tiles) against the oracle, against the per-tap kernel,
+    and reading a channel slice of a wider input"""
     from cfd_amd import ops
     dtype, dev = torch.bfloat16, "cuda"
     if cout % ntile:
@@ -177,6 +181,9 @@ def test_conv_forward_patch_staged(kind, B, H, W, cin, cout, ntile):
     if kind == "convT":
         wk = q(rnd((4, 4, cout, cin), 2, 0.05), dtype)
         wp, code = ops.pack_convT_weight(wk.to(dev), dtype), ops.CONVT_K4S2
+    elif kind == "k4s2":
+        wk = q(rnd((4, 4, cin, cout), 2, 0.05), dtype)
+        wp, code = ops.pack_conv_weight(wk.to(dev), dtype), ops.CONV_K4S2
     else:
         wk = q(rnd((3, 3, cin, cout), 2, 0.05), dtype)
         wp, code = ops.pack_conv_weight(wk.to(dev), dtype), ops.CONV_K3S1
@@ -195,7 +202,7 @@ def test_conv_forward_patch_staged(kind, B, H, W, cin, cout, ntile):
         ops.set_tuning(ops.TUNE_NTILE, -1)
     # (one chunk: both kernels add the same products in the same order; more: chunk-major against tap-major K order,
     #  which also shows that the two launches really ran different kernels)
-    assert torch.equal(a, b) == (cin == 64)
+    assert torch.equal(a, b) == (cin == 64 and kind != "k4s2")      # (stride 2: parity-major against tap-major)
     assert relerr(a.cpu(), b.cpu()) <= 1e-5          # same products, another summation order (chunk-major K)
 
 
@@ -375,6 +382,7 @@ def test_bn_act(B, H, W, C, drop, dtype):
     ("convT", 2, 16, 16, 64, 256, True),    # class grid 256 per sample, dropout (RNG mode)
     ("k4s2", 2, 32, 32, 64, 128, False),    # Cout = 128: 128-wide n tile in both kernels
     ("convT", 2, 16, 32, 128, 256, True),   # whole 8 x 32 tiles: the patch-staged kernel when the 256-wide path is forced
+    ("k4s2", 2, 16, 128, 128, 256, False),  # 8 x 64 output grid: the patch-staged kernel's stride-2 form
 ])
 def test_conv_stats_bn_apply(kind, B, H, W, cin, cout, drop, dtype, force256):
     """BatchNorm statistics fused into the conv epilogue + bn_apply == conv -> oracle BatchNorm (+dropout, acts)"""
