@@ -709,8 +709,9 @@ __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
   if (p.out_bf16) direct_epi(IC<1>{}); else direct_epi(IC<2>{});
 }
 
-// which layers take this path: bf16, a stride-1 tap grid (3x3 'same' conv, or one sub-pixel class of the transposed
-// 4x4 stride-2 conv), whole 256-channel n tiles, no split-K, a class grid that 8 x 32 tiles cover exactly
+// which layers take this path: bf16, a stride-1 tap grid (3x3 'same' conv, one sub-pixel class of the transposed 4x4
+// stride-2 conv, or one input parity of the 4x4 stride-2 conv), whole n tiles, no split-K, a class grid that 8 x 32 tiles
+// cover exactly
 bool igemm256h_eligible(const IgemmParams &p, int dtype, int ntile) {
   if (tuning(CFD_TUNE_PATCH) == 0) return false;
   const bool s1 = (p.kind == CFD_CONV_K3S1 || p.kind == CFD_CONVT_K4S2) && p.Hi == p.Hq && p.Wi == p.Wq;

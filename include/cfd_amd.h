@@ -48,8 +48,8 @@ const char *cfd_last_error(void);
  *                         the same results; it trades distance evaluations per pixel against extra search rings)
  *   CFD_TUNE_NTILE        -1 heuristic | 128 | 256: n tile of the 256-row ping-pong kernels for layers whose Cout is a
  *                         multiple of 256 (128 = the 128(n) x 256(m) variant: twice the blocks, no split-K slabs)
- *   CFD_TUNE_PATCH        -1 / 1 on where legal | 0 off: bf16 3x3 and transposed-4x4 layers on whole 8 x 32 pixel tiles stage
- *                         their activation operand once per 64-channel chunk as an input patch (igemm256h.hip)
+ *   CFD_TUNE_PATCH        -1 / 1 on where legal | 0 off: bf16 3x3, 4x4 stride-2 and transposed-4x4 layers on whole 8 x 32 pixel
+ *                         tiles stage their activation operand once per 64-channel chunk as an input patch (igemm256h.hip)
  */
 typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_WGRAD256 = 2, CFD_TUNE_CLASS_ORDER = 3,
                CFD_TUNE_STAGED_OUT = 4, CFD_TUNE_RESAMPLE_DENSITY = 5, CFD_TUNE_NTILE = 6, CFD_TUNE_PATCH = 7, CFD_TUNE_COUNT = 8 } cfd_tuning_key;
