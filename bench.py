@@ -420,19 +420,45 @@ def main():
     if args.workload is None and not args.no_also:
         # the other BASELINE configs under the same clock: fewer steps each, same contract (warm-up, barrier, max over ranks)
         also = {}
+        out["also"] = also
         k, w = max(3, min(args.steps, 10)), min(args.warmup, 2)
+        # The headline above is measured; nothing below may cost it.  A workload that raises is recorded as an error (and,
+        # with several ranks, ends the extras: the ranks may no longer agree on the next collective); with several ranks a
+        # watchdog prints what has been measured if an extra hangs in a collective.
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def bail():
+                also["watchdog"] = "extras did not finish within 600 s; line printed by the watchdog"
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(600.0 + 5.0 * rank, bail)
+            watchdog.daemon = True
+            watchdog.start()
         for key, wname, B, base in (("infer_all_bf16", "infer_all_bf16", 0, False),
                                     ("train_u_bf16", "train_u_bf16", 16, cpu_base),
                                     ("train_u_bf16_b32", "train_u_bf16", 32, False),
-                                    ("train_deltap_bf16", "train_deltap_bf16", 0, False)):
-            free_device_memory()
-            also[key] = run_model_workload(wname, B, k, w, rank, world, base)
-        free_device_memory()
-        also["resample"] = run_resample_workload(k, w, rank, world, cpu_base)
-        out["also"] = also
+                                    ("train_deltap_bf16", "train_deltap_bf16", 0, False),
+                                    ("resample", None, 0, cpu_base)):
+            try:
+                free_device_memory()
+                if wname is None:
+                    also[key] = run_resample_workload(k, w, rank, world, base)
+                else:
+                    also[key] = run_model_workload(wname, B, k, w, rank, world, base)
+            except Exception as e:   # noqa: BLE001 -- reported in the line, never silently dropped
+                also[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+                if world > 1:
+                    break
+        if watchdog is not None:
+            watchdog.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        if any(isinstance(v, dict) and "error" in v for v in out.get("also", {}).values()):
+            os._exit(0)      # (the ranks may disagree on the next collective: leave without one)
         import torch.distributed as dist
         barrier(world)
         dist.destroy_process_group()
