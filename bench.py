@@ -45,12 +45,17 @@ WORKLOADS = {
 }
 
 
+# Control-flow test hook (tests/test_host_logic_cpu.py): no GPU, gloo ranks, every workload replaced by a canned result
+# marked "dry" -- exercises the spawner, the watchdog and the exit codes, measures nothing.
+DRY = os.environ.get("CFD_BENCH_DRY") == "1"
+
+
 def spawn_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` started plainly: start N ranks as fresh child processes (nothing in this process has
     touched a GPU: torch.cuda.device_count() does not initialise one) and relay their output; rank 0 prints the line."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
+    have = n if DRY else torch.cuda.device_count()
     if have < n:
         print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
         return 2
@@ -63,9 +68,28 @@ def spawn_ranks(n: int, argv) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    # poll all ranks: when one dies the others would sit in their next collective until the RCCL timeout (or for ever),
+    # and this parent with them -- end them and return the first failure's code
     rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    q.terminate()
+                t_end = time.time() + 10.0
+                for q in live:
+                    try:
+                        q.wait(max(0.1, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
     return rc
 
 
@@ -73,6 +97,11 @@ def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if DRY:
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        return rank, world, local
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
@@ -80,11 +109,23 @@ def dist_setup(n_gpus):
     return rank, world, local
 
 
+def dry_workload(name, rank, world):
+    """CFD_BENCH_DRY: one collective per workload (so a rank that never arrives hangs the others, as on RCCL)"""
+    if os.environ.get("CFD_BENCH_HANG_EXTRA") == name and rank == world - 1:
+        time.sleep(3600)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(torch.ones(1))
+    return {"value": 0.0, "unit": "samples/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": 0.0, "dtype": "none",
+            "config": {"workload": name, "dry": True}, "roofline": None}
+
+
 def barrier(world):
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
-    torch.cuda.synchronize()
+    if not DRY:
+        torch.cuda.synchronize()
 
 
 def build_nets(names, tdt):
@@ -177,8 +218,18 @@ def cpu_baseline(names, seconds_budget=20.0):
                 sample=f"{n_done} synthetic 64x512 cases, batch 1 per call, nets {'+'.join(names)}, oracle (PyTorch-CPU fp32)")
 
 
+_cpu_train_cache = {}
+
+
 def cpu_baseline_train(seconds_budget=25.0):
-    """The oracle's U training step (batch 1, reference order U/train.py:116-125) on the host cores."""
+    """The oracle's U training step (batch 1, reference order U/train.py:116-125) on the host cores (timed once per
+    process: every U training workload of the line reports the same figure)."""
+    if "r" not in _cpu_train_cache:
+        _cpu_train_cache["r"] = _cpu_baseline_train(seconds_budget)
+    return dict(_cpu_train_cache["r"])
+
+
+def _cpu_baseline_train(seconds_budget):
     from oracle import nets as O
     from cfd_amd import synthetic
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
@@ -207,18 +258,40 @@ def cpu_baseline_train(seconds_budget=25.0):
                 sample=f"{n} U training steps at batch 1 (G predict + 2 D updates + GAN update), oracle (PyTorch-CPU fp32)")
 
 
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources + this file: identifies the tree a profile was taken on
+    (the GPU box has no .git; scripts/collect_profiles.sh stamps the same digest into every profile it collects)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "cfd_amd", "csrc", "*"))) + [os.path.join(ROOT, "bench.py")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_source(path, summary):
+    """where a PMC-derived figure in the line comes from: NOT this run -- a committed profile of the same command"""
+    return {"file": os.path.relpath(path, ROOT), "git_head": summary.get("git_head"), "csrc_sha16": summary.get("csrc_sha16"),
+            "same_sources_as_this_run": (summary.get("csrc_sha16") == csrc_sha16()) if summary.get("csrc_sha16") else None,
+            "note": "rocprofv3 --pmc passes of this bench command, collected separately (scripts/collect_profiles.sh); "
+                    "not measured in this run"}
+
+
 def pmc_traffic(workload):
     """HBM bytes per launch of the MFMA conv kernels for this workload, from the committed PMC passes
     (profiles/*_<workload>_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same
-    command, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  None when no profile of the workload is committed."""
+    command, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM), the time-weighted MFMA-busy fraction of the same
+    profile, and the profile's identity.  (None, None, None) when no profile of the workload is committed."""
     import glob
     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_summary.json")))
     if not fs:
-        return None, None
+        return None, None, None
     try:
-        ks = json.load(open(fs[-1]))["kernels"]
+        summary = json.load(open(fs[-1]))
+        ks = summary["kernels"]
     except Exception:
-        return None, None
+        return None, None, None
     n = b = 0
     busy = []
     for name, k in ks.items():
@@ -228,9 +301,9 @@ def pmc_traffic(workload):
             if "mfma_busy_frac" in k:
                 busy.append((k["total_us"], k["mfma_busy_frac"]))
     if not n:
-        return None, None
+        return None, None, None
     mb = sum(t * f for t, f in busy) / sum(t for t, _ in busy) if busy else None
-    return round(b / n), (round(mb, 4) if mb is not None else None)
+    return round(b / n), (round(mb, 4) if mb is not None else None), profile_source(fs[-1], summary)
 
 
 def pmc_traffic_resample():
@@ -239,15 +312,16 @@ def pmc_traffic_resample():
     import glob
     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_resample_summary.json")))
     if not fs:
-        return None
+        return None, None
     try:
-        ks = json.load(open(fs[-1]))["kernels"]
+        summary = json.load(open(fs[-1]))
+        ks = summary["kernels"]
         calls = ks["nearest_kernel"]["launches"]
         tot = sum(k["launches"] * (k.get("hbm_read_bytes_per_launch", 0) + k.get("hbm_write_bytes_per_launch", 0))
                   for k in ks.values())
-        return round(tot / calls)
+        return round(tot / calls), profile_source(fs[-1], summary)
     except Exception:
-        return None
+        return None, None
 
 
 def timed_steps(step_fn, steps, warmup, world):
@@ -323,10 +397,10 @@ def run_model_workload(name, B, steps, warmup, rank, world, cpu_base):
         achieved = sm["total_flops"] / (sm["total_ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[wl["dtype"]]
         # the committed PMC passes were taken at the workload's default batch; they say nothing about another one
-        traffic, busy = pmc_traffic(name) if B == wl["batch"] else (None, None)
+        traffic, busy, src = pmc_traffic(name) if B == wl["batch"] else (None, None, None)
         roof = dict(bound="mfma", kernel="igemm256_kernel+igemm_kernel" + ("+wgrad_kernel" if train else ""),
                     achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                    frac=round(achieved / peak, 4), traffic=traffic, mfma_busy_frac_pmc=busy,
+                    frac=round(achieved / peak, 4), traffic=traffic, mfma_busy_frac_pmc=busy, traffic_source=src,
                     launches_per_step=sm["launches"] // n_roof,
                     avg_launch_us=round(sm["total_ms"] * 1e3 / sm["launches"], 2))
     out = {"value": round(world * B * steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": steps,
@@ -335,8 +409,13 @@ def run_model_workload(name, B, steps, warmup, rank, world, cpu_base):
                       "grid": "64x512", "parallelism": (f"dp{world}, RCCL reduce-scatter + sharded Adam + all-gather"
                                                         if train else f"case-sharded x{world}, no collectives")},
            "roofline": roof}
+    if train:
+        out["steps_per_s"] = round(steps / dt, 2)      # configs[0] is quoted per step (the reference's loop is batch 1)
     if cpu_base and rank == 0 and world == 1:
-        out["cpu_baseline"] = cpu_baseline_train() if train else cpu_baseline(wl["nets"])
+        if train and wl["nets"] == ["DeltaP"]:
+            pass                                        # (no oracle timing of the CNN's step: reported without a baseline)
+        else:
+            out["cpu_baseline"] = cpu_baseline_train() if train else cpu_baseline(wl["nets"])
     return out
 
 
@@ -360,10 +439,11 @@ def run_resample_workload(steps, warmup, rank, world, cpu_base, ncase=256):
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b in ev) / n_roof
         gbs = job.algorithmic_bytes() / (ms * 1e-3) / 1e9
+        tr_bytes, tr_src = pmc_traffic_resample()
         roof = dict(bound="hbm", kernel="one cfd_resample_nearest call = init + points_pass + case_setup + bin_count/scan/scatter + "
                                         "nearest_kernel (68 % of the call)",
                     achieved=round(gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 5),
-                    traffic=pmc_traffic_resample(), algorithmic_bytes_per_launch=job.algorithmic_bytes(), avg_launch_us=round(ms * 1e3, 2))
+                    traffic=tr_bytes, traffic_source=tr_src, algorithmic_bytes_per_launch=job.algorithmic_bytes(), avg_launch_us=round(ms * 1e3, 2))
     out = {"value": round(world * ncase * H * W * steps / dt, 1), "unit": "queries/s", "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "dtype": "f64",
            "cases_per_s": round(world * ncase * steps / dt, 1),
@@ -407,61 +487,94 @@ def main():
     rank, world, local = dist_setup(args.gpus)
     cpu_base = not args.no_cpu_baseline
     name = args.workload or "infer_pd_fp32"
-    if name == "resample":
+    out = {"metric": "surrogate samples/sec (infer + train) at 1/2/4/8 GPUs; field rel-err vs CPU ref"}
+    # With several ranks a hang in a collective would otherwise sit until the RCCL timeout (or for ever): a watchdog per
+    # phase prints what HAS been measured (rank 0) and leaves with a NON-ZERO code, naming the workload in flight -- a
+    # hang must never read as a green run.
+    in_flight = {"workload": name, "phase": "headline"}
+    watchdog = [None]
+
+    def arm(seconds):
+        if world == 1:
+            return
+        import threading
+        if watchdog[0] is not None:
+            watchdog[0].cancel()
+
+        def bail():
+            out["watchdog"] = (f"rank {rank}: workload {in_flight['workload']!r} ({in_flight['phase']}) did not finish within "
+                               f"{seconds:.0f} s -- most likely a collective that not every rank reached; line printed by "
+                               f"the watchdog, exit code 3")
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            print(out["watchdog"], file=sys.stderr, flush=True)
+            os._exit(3)
+        watchdog[0] = threading.Timer(seconds + 5.0 * rank, bail)
+        watchdog[0].daemon = True
+        watchdog[0].start()
+
+    wd_s = float(os.environ.get("CFD_BENCH_WATCHDOG_S", "0") or 0)
+    arm(wd_s or 900.0)
+    if DRY:
+        res = dry_workload(name, rank, world)
+    elif name == "resample":
         res = run_resample_workload(args.steps, args.warmup, rank, world, cpu_base)
     else:
         res = run_model_workload(name, args.batch, args.steps, args.warmup, rank, world, cpu_base)
-    out = {"metric": "surrogate samples/sec (infer + train) at 1/2/4/8 GPUs; field rel-err vs CPU ref"}
     out.update({k: res[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")})
     out.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": res["dtype"],
                 "data": "synthetic", "config": res["config"], "roofline": res["roofline"]})
     if "cpu_baseline" in res:
         out["cpu_baseline"] = res["cpu_baseline"]
+    failed = None
     if args.workload is None and not args.no_also:
         # the other BASELINE configs under the same clock: fewer steps each, same contract (warm-up, barrier, max over ranks)
         also = {}
         out["also"] = also
         k, w = max(3, min(args.steps, 10)), min(args.warmup, 2)
-        # The headline above is measured; nothing below may cost it.  A workload that raises is recorded as an error (and,
-        # with several ranks, ends the extras: the ranks may no longer agree on the next collective); with several ranks a
-        # watchdog prints what has been measured if an extra hangs in a collective.
-        watchdog = None
-        if world > 1:
-            import threading
-
-            def bail():
-                also["watchdog"] = "extras did not finish within 600 s; line printed by the watchdog"
-                if rank == 0:
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
-            watchdog = threading.Timer(600.0 + 5.0 * rank, bail)
-            watchdog.daemon = True
-            watchdog.start()
-        for key, wname, B, base in (("infer_all_bf16", "infer_all_bf16", 0, False),
-                                    ("train_u_bf16", "train_u_bf16", 16, cpu_base),
-                                    ("train_u_bf16_b32", "train_u_bf16", 32, False),
-                                    ("train_deltap_bf16", "train_deltap_bf16", 0, False),
-                                    ("resample", None, 0, cpu_base)):
+        # The headline above is measured and is printed whatever happens below.  A workload that raises is recorded as an
+        # error in the line (and, with several ranks, ends the extras: the ranks may no longer agree on the next
+        # collective) -- and the process then exits NON-ZERO (4) after printing the line.
+        for key, wname, B, base in EXTRAS:
+            in_flight.update(workload=key, phase="also")
+            arm(wd_s or 600.0)
             try:
+                if os.environ.get("CFD_BENCH_FAIL_EXTRA") == key:      # test hook: tests/test_host_logic_cpu.py
+                    raise RuntimeError("forced by CFD_BENCH_FAIL_EXTRA")
+                if DRY:
+                    also[key] = dry_workload(key, rank, world)
+                    continue
                 free_device_memory()
                 if wname is None:
-                    also[key] = run_resample_workload(k, w, rank, world, base)
+                    also[key] = run_resample_workload(k, w, rank, world, base and cpu_base)
                 else:
-                    also[key] = run_model_workload(wname, B, k, w, rank, world, base)
+                    also[key] = run_model_workload(wname, B, k, w, rank, world, base and cpu_base)
             except Exception as e:   # noqa: BLE001 -- reported in the line, never silently dropped
                 also[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+                failed = key
                 if world > 1:
                     break
-        if watchdog is not None:
-            watchdog.cancel()
+    if watchdog[0] is not None:
+        watchdog[0].cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if failed is not None:
+        print(f"bench.py: extra workload {failed!r} failed (see its 'error' in the line); exit code 4", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(4)      # (with several ranks they may disagree on the next collective: leave without one)
     if world > 1:
-        if any(isinstance(v, dict) and "error" in v for v in out.get("also", {}).values()):
-            os._exit(0)      # (the ranks may disagree on the next collective: leave without one)
         import torch.distributed as dist
         barrier(world)
         dist.destroy_process_group()
+
+
+# the other workloads of the default line: (key in `also`, workload, per-GPU batch (0 = its default), cpu_baseline?)
+EXTRAS = (("infer_all_bf16", "infer_all_bf16", 0, False),
+          ("train_u_bf16", "train_u_bf16", 16, True),
+          ("train_u_bf16_b32", "train_u_bf16", 32, False),
+          ("train_u_fp32_b1", "train_u_fp32", 1, True),       # BASELINE configs[0]: the reference's own loop shape (batch 1, fp32)
+          ("train_deltap_bf16", "train_deltap_bf16", 0, False),
+          ("resample", None, 0, True))
 
 
 if __name__ == "__main__":

@@ -1,7 +1,23 @@
 // Library-level entry points of libcfd_amd.so.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace cfd {
+int set_max_lds(const void *fn, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, int> done;   // (kernel, device) -> bytes set
+  int dev = 0;
+  CFD_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find({fn, dev});
+  if (it != done.end() && it->second >= bytes) return CFD_OK;
+  CFD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done[{fn, dev}] = bytes;
+  return CFD_OK;
+}
+
 char *last_error_buf() {
   static thread_local char buf[512] = {0};
   return buf;

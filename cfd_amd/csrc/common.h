@@ -13,6 +13,10 @@ namespace cfd {
 // ---- error reporting ---------------------------------------------------------------
 char *last_error_buf();  // thread-local, 512 bytes (api.hip)
 int tuning(int key);     // cfd_set_tuning value, -1 = heuristic (api.hip)
+// hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, bytes), once per (kernel, CURRENT device): HIP keeps the attribute
+// per device function, so a process that drives several GPUs needs it on each; thread-safe (api.hip).  Returns CFD_OK
+// or CFD_EHIP with the error text set.
+int set_max_lds(const void *fn, int bytes);
 
 #define CFD_FAIL(code, ...)                                   \
   do {                                                        \

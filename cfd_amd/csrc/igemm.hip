@@ -460,19 +460,11 @@ static int conv_forward_impl(const cfd_conv_desc *d, const void *x, const void *
     rc = igemm256_launch(p, d->dtype, st);
     if (rc != CFD_OK) return rc;
   } else if (d->dtype == CFD_BF16) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      CFD_HIP(hipFuncSetAttribute((const void *)igemm_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-      attr_done = true;
-    }
+    if (int e_ = set_max_lds((const void *)igemm_kernel<bf16>, (int)shmem)) return e_;
     hipLaunchKernelGGL(igemm_kernel<bf16>, dim3(p.nblocks), dim3(256), shmem, st, p);
     CFD_LAUNCH_CHECK();
   } else {
-    static bool attr_done = false;
-    if (!attr_done) {
-      CFD_HIP(hipFuncSetAttribute((const void *)igemm_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-      attr_done = true;
-    }
+    if (int e_ = set_max_lds((const void *)igemm_kernel<float>, (int)shmem)) return e_;
     hipLaunchKernelGGL(igemm_kernel<float>, dim3(p.nblocks), dim3(256), shmem, st, p);
     CFD_LAUNCH_CHECK();
   }

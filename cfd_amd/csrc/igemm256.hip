@@ -1242,11 +1242,7 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   constexpr bool P_DEFAULT = false;   // until measured: the persistent kernel runs only when asked for
   if (p_legal && (pdt == 36 || pdt == 37 || (P_DEFAULT && pdt < 0 && p.nblocks > 256))) {
     const size_t shp = 2 * ST_BYTES + PART_BYTES;
-    static bool donep = false;
-    if (!donep) {
-      CFD_HIP(hipFuncSetAttribute((const void *)igemm256p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp));
-      donep = true;
-    }
+    if (int e_ = set_max_lds((const void *)igemm256p_kernel, (int)shp)) return e_;
     hipLaunchKernelGGL(igemm256p_kernel, dim3(p_grid), dim3(512), shp, st, P);
     CFD_LAUNCH_CHECK();
     return CFD_OK;
@@ -1255,22 +1251,12 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   // 5, 6 = four phases of 16, prefetch distance 5 / 6 half tiles; 106, 126 = diagnostic builds with cycle stamps
 #define CFD_LAUNCH256(...)                                                                                          \
   do {                                                                                                              \
-    static bool done_ = false;                                                                                      \
-    if (!done_) {                                                                                                   \
-      CFD_HIP(hipFuncSetAttribute((const void *)igemm256_kernel<__VA_ARGS__>,                                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)BIAS256_OFF + 1024));           \
-      done_ = true;                                                                                                 \
-    }                                                                                                               \
+    if (int e_ = set_max_lds((const void *)igemm256_kernel<__VA_ARGS__>, (int)BIAS256_OFF + 1024)) return e_;       \
     hipLaunchKernelGGL((igemm256_kernel<__VA_ARGS__>), dim3(p.nblocks), dim3(512), shmem, st, P);                   \
   } while (0)
   if (ntile == 128) {
     const size_t shmem3 = BIAS128N_OFF + 1024;
-    static bool done3 = false;
-    if (!done3) {
-      CFD_HIP(hipFuncSetAttribute((const void *)igemm128n_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem3));
-      CFD_HIP(hipFuncSetAttribute((const void *)igemm128n_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem3));
-      done3 = true;
-    }
+    if (int e_ = set_max_lds(dtype == CFD_F32 ? (const void *)igemm128n_kernel<float> : (const void *)igemm128n_kernel<bf16>, (int)shmem3)) return e_;
     if (dtype == CFD_F32) hipLaunchKernelGGL(igemm128n_kernel<float>, dim3(p.nblocks), dim3(512), shmem3, st, P);
     else hipLaunchKernelGGL(igemm128n_kernel<bf16>, dim3(p.nblocks), dim3(512), shmem3, st, P);
   } else if (dtype == CFD_F32) CFD_LAUNCH256(float, 6, 0, 4);

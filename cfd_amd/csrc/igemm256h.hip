@@ -764,11 +764,7 @@ int igemm256h_launch(const IgemmParams &pin, int ntile, unsigned xbytes, unsigne
   }
 #define CFD_LAUNCH_H(KERNEL, GEO)                                                                                   \
   do {                                                                                                              \
-    static bool done_ = false;                                                                                      \
-    if (!done_) {                                                                                                   \
-      CFD_HIP(hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, GEO::LDS));     \
-      done_ = true;                                                                                                 \
-    }                                                                                                               \
+    if (int e_ = set_max_lds((const void *)KERNEL, GEO::LDS)) return e_;                                            \
     hipLaunchKernelGGL(KERNEL, dim3(p.nblocks), dim3(512), GEO::LDS, st, P);                                        \
   } while (0)
   typedef HaloGeo<4, true> GeoS2;

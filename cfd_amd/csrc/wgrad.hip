@@ -273,18 +273,10 @@ static int conv_wgrad_impl(const cfd_conv_desc *d, const void *x, const void *dy
   hipStream_t st = (hipStream_t)stream;
   const size_t shmem = 2 * W_STAGE_BYTES;
   if (d->dtype == CFD_BF16) {
-    static bool done = false;
-    if (!done) {
-      CFD_HIP(hipFuncSetAttribute((const void *)wgrad_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-      done = true;
-    }
+    if (int e_ = set_max_lds((const void *)wgrad_kernel<bf16>, (int)shmem)) return e_;
     hipLaunchKernelGGL(wgrad_kernel<bf16>, dim3(p.nblocks), dim3(256), shmem, st, p);
   } else {
-    static bool done = false;
-    if (!done) {
-      CFD_HIP(hipFuncSetAttribute((const void *)wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-      done = true;
-    }
+    if (int e_ = set_max_lds((const void *)wgrad_kernel<float>, (int)shmem)) return e_;
     hipLaunchKernelGGL(wgrad_kernel<float>, dim3(p.nblocks), dim3(256), shmem, st, p);
   }
   CFD_LAUNCH_CHECK();

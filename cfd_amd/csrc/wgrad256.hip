@@ -351,12 +351,10 @@ int wgrad256_launch(Wgrad256Params &p, const void *x, const void *dy, float *dw,
   CFD_REQUIRE(p.dw_elems < (1LL << 31), "weight tensor too large for 32-bit element offsets");
   p.slab = p.split_m > 1 ? workspace : nullptr;
   const size_t shmem = 2 * WST;
-  static bool done = false;
-  if (!done) {
-    CFD_HIP(hipFuncSetAttribute((const void *)wgrad256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    CFD_HIP(hipFuncSetAttribute((const void *)wgrad256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    CFD_HIP(hipFuncSetAttribute((const void *)wgrad256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    done = true;
+  {
+    const void *fn = p.gather_a ? (const void *)wgrad256_kernel<true, false>
+                                : (p.pair ? (const void *)wgrad256_kernel<false, true> : (const void *)wgrad256_kernel<false, false>);
+    if (int e_ = set_max_lds(fn, (int)shmem)) return e_;
   }
   CFD_REQUIRE(!(p.pair && p.gather_a), "tap pairs need a gathered ci-side operand");
   if (p.gather_a) hipLaunchKernelGGL((wgrad256_kernel<true, false>), dim3(p.nblocks), dim3(512), shmem, st, p);

@@ -613,7 +613,11 @@ def load_model(filepath, compile=True, custom_objects=None):
     """keras.models.load_model counterpart: reads the archives save_model above writes (HDF5 or npz member) AND `.keras`
     archives written by Keras 3 itself for the four reference graphs (U/train.py:198-203): the graph is recognised from
     the shapes in `model.weights.h5`, the image shape from the InputLayer in Keras' config.json, the optimizer state
-    from `optimizer/vars/*` (compile=True).  custom_objects (the MC_* losses) is accepted and not needed."""
+    from `optimizer/vars/*` (compile=True).  custom_objects (the MC_* losses) is accepted and not needed.
+    PARITY UNPINNED for Keras-written archives: the variable order assumed below -- [iterations, learning_rate, then
+    (momentum, velocity) per trainable variable; for the composite GAN all of G's variables before D's BatchNorm
+    gamma / beta] -- is Keras 3's published rule, never checked against a file Keras wrote (none exists here).  Shapes
+    are verified per name; two same-shaped tensors listed in another order (e.g. D before G) would be assigned silently."""
     filepath = str(filepath)
     with zipfile.ZipFile(filepath) as z:
         names = set(z.namelist())

@@ -33,7 +33,7 @@ _BN_VARS = ("gamma", "beta", "moving_mean", "moving_var")
 
 
 def _layer_bases(specs) -> List[str]:
-    """layer prefixes in graph order (the ParamStore keeps kernels in creation order inside their group)"""
+    """layer prefixes in graph order (ParamStore.specs iterates in declaration order, whatever the offsets)"""
     return [n[:-len(".kernel")] for n in specs if n.endswith(".kernel")]
 
 

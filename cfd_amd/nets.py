@@ -142,6 +142,7 @@ class _Net:
     def check_image(self, *imgs: torch.Tensor) -> None:
         """every image operand must be the fp32 (B, H, W, 1) grid this net was built for: the layer buffers are sized
         from (H, W) and the kernels do not bounds-check"""
+        self.params.join_updates()      # (every forward / backward starts here) parameter all-gathers still in flight
         B = imgs[0].shape[0]
         for t in imgs:
             if tuple(t.shape) != (B, self.H, self.W, 1) or t.dtype != torch.float32 or not t.is_cuda:

@@ -3,9 +3,12 @@
 dtype for the MFMA operands.  Keras layouts appear only at the interchange boundary
 (`load_keras` / `to_keras`, used by checkpoints, get/set_weights and the parity tests).
 
-Order inside the flat buffer: trainable non-BN tensors, then BN gamma/beta (one contiguous range,
-because `define_gan` leaves exactly those of D trainable, U/models/generator.py:79-81), then the
-non-trainable moving statistics.  Every tensor starts on a 512-element boundary: 16-B vector loads (bias,
+Order inside the flat buffer: the GEMM kernels (read by the MFMA kernels through the compute-dtype shadow), then
+the small tensors every kernel reads in fp32 straight from the master -- biases and the first layers' kernels
+(Cin <= 2: conv_first) --, then BN gamma/beta (one contiguous range, because `define_gan` leaves exactly those
+of D trainable, U/models/generator.py:79-81), then the non-trainable moving statistics.  [0, n_kernels) is the only
+range the data-parallel step shards: a rank's fp32 master of chunks it does not own goes stale there, which nothing
+in a forward or backward reads; [n_kernels, n_trainable) is updated replicated on every rank (trainer._DP).  Every tensor starts on a 512-element boundary: 16-B vector loads (bias,
 gamma) and a single fused Adam launch over the trainable prefix stay aligned, and every range between
 two layer boundaries divides into 2, 4 or 8 chunks of whole 64-element groups -- the reduce-scatter /
 sharded-Adam / all-gather data-parallel step (trainer._DP) splits such ranges by rank.
@@ -43,33 +46,46 @@ class Spec:
         self.offset = -1
 
 
-def _group(kind: str, name: str) -> int:
-    if kind == "stat":
+def _group(s: "Spec") -> int:
+    if s.kind == "stat":
+        return 3
+    if s.kind == "bn":
         return 2
-    if kind == "bn":
-        return 1
+    if s.kind == "vec" or (s.kind == "conv" and s.keras_shape[2] <= 2):
+        return 1          # read in fp32 from the master by the kernels (biases; conv_first's weights)
     return 0
 
 
 class ParamStore:
     def __init__(self, specs: List[Spec], device, compute_dtype: torch.dtype):
         self.device, self.compute_dtype = torch.device(device), compute_dtype
-        ordered = sorted(range(len(specs)), key=lambda i: (_group(specs[i].kind, specs[i].name), i))
-        self.specs: "OrderedDict[str, Spec]" = OrderedDict()
+        ordered = sorted(range(len(specs)), key=lambda i: (_group(specs[i]), i))
+        # `specs` keeps the DECLARATION order (= graph order: keras_h5 and the Keras surface's `.layers` walk it);
+        # offsets follow the group order
+        self.specs: "OrderedDict[str, Spec]" = OrderedDict((s.name, s) for s in specs)
         off = 0
-        bounds = [0, 0, 0]
+        bounds = [0, 0, 0, 0]
         for i in ordered:
             s = specs[i]
             s.offset = off
             off += (s.numel + ALIGN - 1) // ALIGN * ALIGN
-            self.specs[s.name] = s
-            bounds[_group(s.kind, s.name)] = off
-        self.n_main = bounds[0]                       # [0, n_main): conv/dense kernels + biases
-        self.n_trainable = max(bounds[0], bounds[1])  # [n_main, n_trainable): BN gamma/beta
+            for k in range(_group(s), 4):
+                bounds[k] = off
+        self.n_kernels = bounds[0]                    # [0, n_kernels): GEMM kernels (layer order)
+        self.n_main = bounds[1]                       # [n_kernels, n_main): biases + first-layer kernels
+        self.n_trainable = bounds[2]                  # [n_main, n_trainable): BN gamma/beta
         self.n_total = off
+        self._pending_updates: List = []              # events of parameter all-gathers in flight (trainer._DP)
         self.master = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.compute = self.master if compute_dtype == torch.float32 else \
             torch.zeros(self.n_trainable, dtype=compute_dtype, device=self.device)
+
+    # ---- asynchronous parameter updates (data-parallel step) --------------------------------
+    def join_updates(self) -> None:
+        """the current stream waits for every parameter all-gather of the last optimiser step still in flight
+        (trainer._DP.gather_async); every forward, the transposed-weight refresh and sync_state call it"""
+        for ev in self._pending_updates:
+            torch.cuda.current_stream().wait_event(ev)
 
     # ---- views -------------------------------------------------------------------------
     def m(self, name: str) -> torch.Tensor:
@@ -122,6 +138,7 @@ class ParamStore:
             self._transpose_all()
 
     def _transpose_all(self) -> None:
+        self.join_updates()
         for name, s in self.specs.items():
             if s.kind in ("conv", "convT", "dense") and name not in self.no_transpose:
                 flip = s.kind == "conv" and s.packed_shape[1] * s.packed_shape[2] in (9,) or name in self.flip_taps
@@ -139,7 +156,7 @@ class ParamStore:
         over a device-resident range table instead of a memset of the whole flat buffer."""
         if self._zero_table is None:
             ranges = []
-            for name, s in self.specs.items():
+            for name, s in sorted(self.specs.items(), key=lambda kv: kv[1].offset):
                 if s.offset >= self.n_trainable or name in self.stored_grads:
                     continue
                 span = (s.numel + ALIGN - 1) // ALIGN * ALIGN            # the padding behind a tensor may be cleared too

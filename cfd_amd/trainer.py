@@ -35,24 +35,30 @@ class Adam:
         self.m = torch.zeros(n, dtype=torch.float32, device=params.device)
         self.v = torch.zeros(n, dtype=torch.float32, device=params.device)
 
+    def begin(self) -> float:
+        """start update t + 1: returns its step size alpha_t (Keras: lr * sqrt(1 - b2^t) / (1 - b1^t))"""
+        self.t += 1
+        return self.lr * math.sqrt(1.0 - ADAM_BETA_2 ** self.t) / (1.0 - self.b1 ** self.t)
+
+    def apply(self, a: int, b: int, g, alpha: float, grad_scale: float = 1.0) -> None:
+        """update the absolute range [a, b) inside [lo, hi) with gradient `g` (compact tensor of b - a elements, or None
+        = params.grad[a:b]).  The sharded data-parallel step hands in this rank's chunks, so Adam's 7 x 4 B + 2 B per
+        parameter shrink by the world size."""
+        if not (self.lo <= a <= b <= self.hi):
+            raise ValueError(f"Adam segment [{a}, {b}) outside the optimiser's range [{self.lo}, {self.hi})")
+        if b == a:
+            return
+        P = self.p
+        wc = None if P.compute is P.master else P.compute[a:b]
+        ops.adam_step(P.master[a:b], P.grad[a:b] if g is None else g, self.m[a - self.lo:b - self.lo],
+                      self.v[a - self.lo:b - self.lo], wc, alpha, self.b1, ADAM_BETA_2, ADAM_EPS, grad_scale)
+
     def step(self, grad_scale: float = 1.0, segments=None) -> None:
         """One update of [lo, hi).  `segments` = None: the whole range, gradient read from params.grad.  Otherwise a
-        list of (a, b, g) -- absolute ranges [a, b) inside [lo, hi) with their (summed) gradient in the compact tensor
-        `g` (or None = params.grad[a:b]): only those ranges are touched.  The sharded data-parallel step hands in this
-        rank's chunks (`_DP.take`), so Adam's 7 x 4 B + 2 B per parameter shrink by the world size."""
-        self.t += 1
-        alpha = self.lr * math.sqrt(1.0 - ADAM_BETA_2 ** self.t) / (1.0 - self.b1 ** self.t)
-        P = self.p
-        if segments is None:
-            segments = [(self.lo, self.hi, None)]
-        for a, b, g in segments:
-            if not (self.lo <= a <= b <= self.hi):
-                raise ValueError(f"Adam segment [{a}, {b}) outside the optimiser's range [{self.lo}, {self.hi})")
-            if b == a:
-                continue
-            wc = None if P.compute is P.master else P.compute[a:b]
-            ops.adam_step(P.master[a:b], P.grad[a:b] if g is None else g, self.m[a - self.lo:b - self.lo],
-                          self.v[a - self.lo:b - self.lo], wc, alpha, self.b1, ADAM_BETA_2, ADAM_EPS, grad_scale)
+        list of (a, b, g) as for apply(): only those ranges are touched."""
+        alpha = self.begin()
+        for a, b, g in ([(self.lo, self.hi, None)] if segments is None else segments):
+            self.apply(a, b, g, alpha, grad_scale)
 
 
 def _cast(src: torch.Tensor, dst: torch.Tensor) -> None:
@@ -65,18 +71,46 @@ def _cast(src: torch.Tensor, dst: torch.Tensor) -> None:
         dst.copy_(src)
 
 
+_side_stream = None
+
+
+def _dp_stream():
+    """ONE side stream per process for every collective launch: the discriminator's and the composite's trainers each
+    own a _DP, and their collectives must reach RCCL in one program order on every rank"""
+    global _side_stream
+    if _side_stream is None:
+        _side_stream = torch.cuda.Stream()
+    return _side_stream
+
+
+class _Seg:
+    """one range [a, b) of the flat gradient buffer handed to a collective this step"""
+    __slots__ = ("a", "b", "gs", "g16", "handles")
+
+    def __init__(self, a, b, gs, g16):
+        self.a, self.b, self.gs, self.g16, self.handles = a, b, gs, g16, []
+
+
 class _DP:
     """Gradient exchange of the data-parallel step over RCCL (`torch.distributed`); a no-op for world size 1.
 
     Two forms, chosen per range of the flat gradient buffer:
-      * sharded (default for world in {2, 4, 8} and ranges of at least `shard_min` elements): `reduce_scatter_tensor`
-        leaves rank r with the sum of chunk r of the range, Adam updates only that chunk (optimizer traffic / world),
-        and `all_gather_into_tensor` redistributes the updated COMPUTE copy (bf16 in bf16 mode: 2 B per parameter on
-        the wire instead of 4).  On the fully connected xGMI node every rank sends a chunk to every peer at once, so
-        all seven links carry data in both phases.  The fp32 master (and Adam's m, v) of the chunks a rank does not own
-        go stale until `sync_state()` (a collective: every rank calls it) -- checkpoints call it.
-      * replicated: bucketed `all_reduce` (SUM), every rank applies the same Adam step (small ranges, other world sizes,
-        CFD_AMD_DP_SHARD=0).
+      * sharded (default for world in {2, 4, 8}; ranges of at least `shard_min` elements INSIDE [0, P.n_kernels), the
+        GEMM kernels): `reduce_scatter_tensor` leaves rank r with the sum of chunk r of the range, Adam updates only
+        that chunk (optimizer traffic / world), and `all_gather_into_tensor` redistributes the updated COMPUTE copy
+        (bf16 in bf16 mode: 2 B per parameter on the wire instead of 4).  On the fully connected xGMI node every rank
+        sends a chunk to every peer at once, so all seven links carry data in both phases.  The fp32 master (and
+        Adam's m, v) of the chunks a rank does not own go stale until `sync_state()` (a collective: every rank calls
+        it) -- checkpoints call it.  Nothing in a forward or backward reads the master of that range: every tensor the
+        kernels read in fp32 (biases, the first layers' kernels, BatchNorm gamma / beta) lies in
+        [P.n_kernels, P.n_trainable), which is ALWAYS updated replicated, so the replicas stay coherent.
+      * replicated: bucketed `all_reduce` (SUM), every rank applies the same Adam step (the fp32-read range above, small
+        ranges, other world sizes, CFD_AMD_DP_SHARD=0).
+    Per bucket: `apply()` makes the compute stream wait for ONE range's collective, runs Adam on it and hands the
+    updated chunk straight to an asynchronous all-gather on the side stream -- the first Adam segment starts when the
+    first reduce-scatter (the last layers' gradients, launched from inside the backward) is done, not when all are, and
+    the all-gathers overlap the remaining Adam segments and whatever the caller enqueues next; the next reader of the
+    parameters waits for them (`ParamStore.join_updates`, called by every forward).
     CFD_AMD_DP_GRAD_BF16=1 exchanges the gradients in bf16 (half the bytes; the sum of `world` bf16 terms then carries
     bf16 rounding -- off by default, covered by a tolerance test).
     ParamStore aligns every tensor to 512 elements, so every range between layer boundaries divides by world * 64."""
@@ -94,9 +128,8 @@ class _DP:
         self.shard = self.shard and self.world in (2, 4, 8)
         self.shard_min = shard_min
         self.grad_bf16 = (os.environ.get("CFD_AMD_DP_GRAD_BF16", "0") == "1") if grad_bf16 is None else bool(grad_bf16)
-        self.handles: List = []
-        self.stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
-        self._segs = {}        # id(params) -> ranges handed over this step: (a, b, shard tensor | None, 16-bit staging | None)
+        self.stream = _dp_stream() if (self.world > 1 and torch.cuda.is_available()) else None
+        self._segs = {}        # id(params) -> [_Seg]: ranges handed over this step
         self._pool = {}        # id(params) -> dict of grow-only scratch tensors
         self.partition = {}    # id(params) -> {(a, b)}: every range that has ever been updated sharded (for sync_state)
 
@@ -111,7 +144,7 @@ class _DP:
     def _launch(self, fn) -> None:
         """run the collective launches of `fn` behind everything already enqueued on the current stream, on the side
         stream (GPU), so that they overlap what the caller enqueues next"""
-        if self.stream is None:          # gloo / CPU tests
+        if self.stream is None:          # gloo / CPU tests, virtual ranks
             fn()
             return
         ev = torch.cuda.Event()
@@ -120,25 +153,32 @@ class _DP:
             self.stream.wait_event(ev)
             fn()
 
-    def reduce_async(self, flat: torch.Tensor) -> None:
-        """launch the bucketed all-reduce of `flat` (already fully written on the current stream)"""
+    def reduce_async(self, flat: torch.Tensor, handles: Optional[List] = None) -> List:
+        """launch the bucketed all-reduce of `flat` (already fully written on the current stream); returns the handles"""
+        handles = [] if handles is None else handles
         if self.world == 1:
-            return
+            return handles
 
         def go():
             for s in range(0, flat.numel(), self.bucket):
-                self.handles.append(self.dist.all_reduce(flat[s:s + self.bucket], async_op=True))
+                handles.append(self.dist.all_reduce(flat[s:s + self.bucket], async_op=True))
         self._launch(go)
+        return handles
 
     def reduce_range_async(self, P, a: int, b: int) -> None:
         """hand params.grad[a:b) (final on the current stream) to the collective: reduce-scatter when the range is
-        eligible for the sharded update, all-reduce otherwise.  `take(P, ...)` returns the matching Adam segments."""
+        eligible for the sharded update, all-reduce otherwise.  `apply(P, opt)` runs the matching Adam segments."""
         if self.world == 1 or b <= a:
+            return
+        nk = getattr(P, "n_kernels", b)
+        if a < nk < b:                                    # never shard across the fp32-read range
+            self.reduce_range_async(P, a, nk)
+            self.reduce_range_async(P, nk, b)
             return
         n = b - a
         segs = self._segs.setdefault(id(P), [])
-        off = sum(x[1] - x[0] for x in segs)              # bump pointer into this step's scratch
-        if self.shard and n >= self.shard_min and n % (self.world * 64) == 0:
+        off = sum(x.b - x.a for x in segs)                # bump pointer into this step's scratch
+        if self.shard and b <= nk and n >= self.shard_min and n % (self.world * 64) == 0:
             c = n // self.world
             if self.grad_bf16:
                 src = self._scratch(P, "g16", P.n_trainable, torch.bfloat16)[a:b]
@@ -149,73 +189,84 @@ class _DP:
                 dst = None
             gs = self._scratch(P, "s32", P.n_trainable // self.world + 64, torch.float32)[off // self.world:off // self.world + c]
             out = gs if dst is None else dst
-            self._launch(lambda: self.handles.append(self.dist.reduce_scatter_tensor(out, src, async_op=True)))
-            segs.append((a, b, gs, dst))
+            seg = _Seg(a, b, gs, dst)
+            self._launch(lambda: seg.handles.append(self.dist.reduce_scatter_tensor(out, src, async_op=True)))
             self.partition.setdefault(id(P), set()).add((a, b))
         else:
+            seg = _Seg(a, b, None, None)
             if self.grad_bf16:
-                g16 = self._scratch(P, "g16", P.n_trainable, torch.bfloat16)[a:b]
-                _cast(P.grad[a:b], g16)
-                self.reduce_async(g16)
-                segs.append((a, b, None, g16))
+                seg.g16 = self._scratch(P, "g16", P.n_trainable, torch.bfloat16)[a:b]
+                _cast(P.grad[a:b], seg.g16)
+                self.reduce_async(seg.g16, seg.handles)
             else:
-                self.reduce_async(P.grad[a:b])
-                segs.append((a, b, None, None))
+                self.reduce_async(P.grad[a:b], seg.handles)
+        segs.append(seg)
 
     def wait(self) -> None:
-        for h in self.handles:
-            h.wait()
-        self.handles.clear()
-        if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
+        """the current stream waits for every collective launched through reduce_range_async so far (apply() waits
+        range by range instead; this is for callers that only want the summed gradients)"""
+        for segs in self._segs.values():
+            for sg in segs:
+                for h in sg.handles:
+                    h.wait()
+                sg.handles = []
 
     def chunk(self, a: int, b: int):
         """this rank's chunk of a sharded range"""
         c = (b - a) // self.world
         return a + self.rank * c, a + (self.rank + 1) * c
 
-    def take(self, P, lo: int, hi: int):
-        """After wait(): the Adam segments of the ranges handed over this step that lie in [lo, hi) -- this rank's
-        chunk with its compact summed gradient for a sharded range, the whole range for a replicated one -- or None for
-        world size 1 (Adam then runs over its whole range)."""
+    def apply(self, P, opt: "Adam") -> None:
+        """One optimiser step of `opt` over the ranges of P handed over this step (they must cover [opt.lo, opt.hi)
+        exactly), bucket by bucket in the order they were launched: wait for that range's collective only, Adam on this
+        rank's chunk (sharded) or on the whole range (replicated), then -- sharded -- start the asynchronous all-gather
+        of the updated compute copy.  World size 1: plain Adam over the optimiser's range."""
         if self.world == 1:
-            return None
-        segs = self._segs.get(id(P), [])
-        mine = [x for x in segs if lo <= x[0] and x[1] <= hi]
-        self._segs[id(P)] = [x for x in segs if not (lo <= x[0] and x[1] <= hi)]
-        covered = sum(x[1] - x[0] for x in mine)
-        if covered != hi - lo:
-            raise RuntimeError(f"data-parallel step: gradient ranges handed over cover {covered} of the {hi - lo} "
-                               f"elements of the optimiser's range [{lo}, {hi})")
-        out = []
-        for a, b, gs, g16 in mine:
-            if gs is not None:
-                if g16 is not None:
-                    _cast(g16, gs)
-                ca, cb = self.chunk(a, b)
-                out.append((ca, cb, gs))
-            else:
-                if g16 is not None:
-                    _cast(g16, P.grad[a:b])
-                out.append((a, b, None))
-        return out
-
-    def gather_params(self, P, segments) -> None:
-        """after Adam: every rank's updated chunk of the compute copy -> all ranks (sharded segments only)"""
-        if self.world == 1 or not segments:
+            opt.step()
             return
-        c = self.world
-        for ca, cb, gs in segments:
-            if gs is None:
-                continue
-            n = (cb - ca) * c
-            a = ca - self.rank * (cb - ca)
-            self._all_gather(P.compute, a, a + n, P, "ag")
+        segs = self._segs.get(id(P), [])
+        mine = [x for x in segs if opt.lo <= x.a and x.b <= opt.hi]
+        self._segs[id(P)] = [x for x in segs if not (opt.lo <= x.a and x.b <= opt.hi)]
+        covered = sum(x.b - x.a for x in mine)
+        if covered != opt.hi - opt.lo:
+            raise RuntimeError(f"data-parallel step: gradient ranges handed over cover {covered} of the {opt.hi - opt.lo} "
+                               f"elements of the optimiser's range [{opt.lo}, {opt.hi})")
+        alpha = opt.begin()
+        P._pending_updates = []        # (the forward of the step that produced these gradients joined the previous ones)
+        for sg in mine:
+            for h in sg.handles:
+                h.wait()               # the CURRENT stream waits for this range's collective (no host block on RCCL)
+            sg.handles = []
+            if sg.gs is not None:
+                if sg.g16 is not None:
+                    _cast(sg.g16, sg.gs)
+                ca, cb = self.chunk(sg.a, sg.b)
+                opt.apply(ca, cb, sg.gs, alpha, self.grad_scale)
+                self.gather_async(P, P.compute, sg.a, sg.b)
+            else:
+                if sg.g16 is not None:
+                    _cast(sg.g16, P.grad[sg.a:sg.b])
+                opt.apply(sg.a, sg.b, None, alpha, self.grad_scale)
+
+    def gather_async(self, P, T: torch.Tensor, a: int, b: int) -> None:
+        """every rank's chunk of T[a:b) -> all ranks, on the side stream; readers wait through P.join_updates()"""
+        ca, cb = self.chunk(a, b)
+        stage = self._scratch(P, ("ag", a, T.dtype), cb - ca, T.dtype)   # one per range: several are in flight at once
+        stage.copy_(T[ca:cb])             # the send buffer must not alias the receive buffer on every backend
+
+        def go():
+            h = self.dist.all_gather_into_tensor(T[a:b], stage, async_op=True)
+            h.wait()                      # the side stream (not the compute stream) waits for the collective
+            if self.stream is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                P._pending_updates.append(ev)
+        self._launch(go)
 
     def _all_gather(self, T: torch.Tensor, a: int, b: int, P, key: str) -> None:
         ca, cb = self.chunk(a, b)
         stage = self._scratch(P, key + str(T.dtype), cb - ca, T.dtype)
-        stage.copy_(T[ca:cb])             # the send buffer must not alias the receive buffer on every backend
+        stage.copy_(T[ca:cb])
         self.dist.all_gather_into_tensor(T[a:b], stage)
 
     def sync_state(self, P, opts=()) -> None:
@@ -225,6 +276,8 @@ class _DP:
         if self.world == 1:
             return
         join_averages()
+        if hasattr(P, "join_updates"):
+            P.join_updates()
         for a, b in sorted(self.partition.get(id(P), ())):
             if P.compute is not P.master:
                 self._all_gather(P.master, a, b, P, "ag")
@@ -291,22 +344,25 @@ def sync_from_rank0(dp: _DP, params, opts=()) -> None:
 
 
 class BackwardBuckets:
-    """Overlap of the gradient exchange with the backward pass.  The main range [0, n_main) of the flat
-    gradient buffer holds kernels and biases in layer order (e1 .. out) and the backward runs last layer first, so
+    """Overlap of the gradient exchange with the backward pass.  The range [0, n_kernels) of the flat
+    gradient buffer holds the GEMM kernels in layer order (e2 .. out) and the backward runs last layer first, so
     when layer L reports ready everything in [offset(L.kernel), hi) is final: that tail is handed to RCCL on the side
     stream (once it holds at least `min_elems`, to keep collectives large) while the earlier layers' gradient
-    kernels keep running.  `finish()` sends what is left plus the BatchNorm range.  The cut points depend only on the
+    kernels keep running.  `finish()` sends what is left plus the small replicated range (biases, first-layer kernel,
+    BatchNorm gamma / beta).  The cut points depend only on the
     layer sizes, so the sharded update owns the same chunks every step."""
 
     def __init__(self, dp: _DP, params, min_elems: int = 8 * 1024 * 1024):
         self.dp, self.p, self.min = dp, params, min_elems
-        self.hi = params.n_main
+        self.hi = getattr(params, "n_kernels", params.n_main)
         self.sent: List[tuple] = []          # (lo, hi) ranges handed to the collective, for tests
 
     def ready(self, layer: str) -> None:
         if self.dp.world == 1:
             return
         lo = self.p.specs[layer + ".kernel"].offset
+        if lo >= self.hi:               # a first-layer kernel: it lives in the fp32-read range that finish() sends
+            return
         if self.hi - lo >= self.min or lo == 0:
             self._send(lo, self.hi)
             self.hi = lo
@@ -321,7 +377,7 @@ class BackwardBuckets:
             return
         self._send(0, self.hi)
         self.hi = 0
-        self._send(self.p.n_main, self.p.n_trainable)
+        self._send(getattr(self.p, "n_kernels", self.p.n_main), self.p.n_trainable)
 
 
 def _side_wgrad(dp) -> bool:
@@ -369,9 +425,7 @@ class DiscriminatorTrainer:
         dz = d.buf(d.plan(B), "dlogits", logits.shape, torch.float32)
         ops.bce_logits(logits, self._loss_out, dz, target_const=label)
         d.backward(dz, src, tgt, train_convs=self.train_convs, side_wgrad=_side_wgrad(self.dp))
-        if self.opt.lo < P.n_main:
-            self.dp.reduce_range_async(P, self.opt.lo, P.n_main)
-        self.dp.reduce_range_async(P, max(self.opt.lo, P.n_main), self.opt.hi)
+        self.dp.reduce_range_async(P, self.opt.lo, self.opt.hi)      # (split at n_kernels: sharded | replicated)
         self._pending = B
 
     def finish(self, sync: bool = True):
@@ -381,11 +435,8 @@ class DiscriminatorTrainer:
         B, self._pending = self._pending, None
         if B is None:
             raise RuntimeError("finish() without begin()")
-        self.dp.wait()
         P = self.d.params
-        segs = self.dp.take(P, self.opt.lo, self.opt.hi)
-        self.opt.step(self.dp.grad_scale, segs)
-        self.dp.gather_params(P, segs)
+        self.dp.apply(P, self.opt)
         if self.train_convs:
             P.refresh_transposed(side_stream=True)
         join_averages()
@@ -452,11 +503,8 @@ class GanTrainer:
         g.backward(dz, src, masks=masks, seed=seed, sample0=sample0, ready=buckets.ready,
                    side_wgrad=_side_wgrad(self.dp))
         buckets.finish()
-        self.dp.wait()
-        segs = self.dp.take(g.params, self.opt_g.lo, self.opt_g.hi)
-        self.opt_g.step(self.dp.grad_scale, segs)
-        self.dp.gather_params(g.params, segs)
-        self.opt_dbn.step(self.dp.grad_scale, self.dp.take(d.params, self.opt_dbn.lo, self.opt_dbn.hi))
+        self.dp.apply(g.params, self.opt_g)          # per bucket: wait, Adam, asynchronous all-gather
+        self.dp.apply(d.params, self.opt_dbn)
         g.params.refresh_transposed(side_stream=True)
         join_averages()
         d.update_moving(B)
@@ -501,10 +549,7 @@ class CnnTrainer:
         ops.field_loss(pred, y, ops.HUBER, self.loss, dy, weight=self.weight, delta=self.delta)
         c.backward(dy, x, drop_mask=drop_mask, seed=seed, sample0=sample0)
         self.dp.reduce_range_async(P, 0, P.n_trainable)
-        self.dp.wait()
-        segs = self.dp.take(P, 0, P.n_trainable)
-        self.opt.step(self.dp.grad_scale, segs)
-        self.dp.gather_params(P, segs)
+        self.dp.apply(P, self.opt)
         P.refresh_transposed(side_stream=True)
         return self.weight * float(self.loss.item())
 

@@ -50,6 +50,20 @@ def newest(pattern):
 
 
 out = {"tag": tag, "kernels": {}}
+# which tree the passes ran on: the digest collect_profiles.sh took ON THE BOX, and the commit (passed in through
+# CFD_GIT_HEAD, else HEAD here at summary time, flagged when the work tree has uncommitted changes)
+try:
+    out.update(json.load(open(os.path.join(src, "source_stamp.json"))))
+except Exception:
+    pass
+if not out.get("git_head"):
+    import subprocess
+    try:
+        head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip()
+        dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "cfd_amd", "bench.py"], cwd=root, capture_output=True, text=True).stdout.strip())
+        out["git_head"] = head + ("+uncommitted" if dirty else "")
+    except Exception:
+        out["git_head"] = None
 st = newest("stats/**/*_kernel_stats.csv")
 if st:
     shutil.copy(st, os.path.join(dst, f"{rnd}_{tag}_kernel_stats.csv"))

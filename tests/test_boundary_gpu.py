@@ -42,8 +42,10 @@ def test_models_namespace_matches_reference():
         sys.modules.pop("models", None)
 
 
-@pytest.mark.parametrize("field", ["U", "DeltaP"])
+@pytest.mark.parametrize("field", ["U", "P", "DeltaP"])
 def test_train_resume_evaluate(field, tmp_path, monkeypatch):
+    """<field>/train.py -n 1, resume, valid.py, test.py end to end.  P: the targets are divided by the training
+    set's maximum (P/train.py:79-82) and the GAN step is the U script's (P/train.py:117-146)."""
     from cfd_amd import cli, keras_api as K
     folder = make_processed_folder(tmp_path, 20)
     monkeypatch.chdir(tmp_path)
@@ -52,7 +54,7 @@ def test_train_resume_evaluate(field, tmp_path, monkeypatch):
     assert (out / "steps.txt").read_text() == "18"            # 20 cases -> 18 train / 2 valid, batch 1
     assert len(np.loadtxt(out / "train_indices.txt")) == 18 and len(np.loadtxt(out / "valid_indices.txt")) == 2
     assert (out / "model_ckpt" / "model_G.keras").exists()
-    if field == "U":
+    if field in ("U", "P"):
         assert (out / "model_ckpt" / "model_D.keras").exists() and (out / "model_ckpt" / "model_GAN.keras").exists()
         assert (out / "model_eval.keras").exists()
     assert len(hist["g"]) == 1 and np.isfinite(hist["g"][0]) and np.isfinite(hist["val"][0])
@@ -199,6 +201,76 @@ def _keras_style_archive(path, datasets, image_shape, empty=()):
         z.writestr("config.json", json.dumps(cfg))
         z.write(tmp, "model.weights.h5")
     os.remove(tmp)
+
+
+def _golden_fill(var_id, shape, positive=False):
+    """the content formula of tests/golden/make_keras_archive.py, restated (data, not layout)"""
+    n = int(np.prod(shape)) if len(shape) else 1
+    v = ((np.arange(n, dtype=np.int64) * 7919 + var_id * 104729) % 2003).astype(np.float32) / 2003.0 - 0.5
+    v = v * 0.05
+    if positive:
+        v = np.abs(v) + 0.01
+    return v.reshape(shape)
+
+
+def test_load_model_reads_hand_laid_out_archive(tmp_path, monkeypatch):
+    """(f3) without testing the reader with the writer: tests/golden/make_keras_archive.py lays out `.keras` archives of
+    the DeltaP CNN and the discriminator with every HDF5 path and the optimizer's variable order TYPED OUT from Keras 3's
+    published saving rule, imports nothing from this repository and writes with h5py under the image's conda
+    interpreter.  load_model must put dataset k into the tensor this test names -- also literally -- for it.  Still
+    unpinned against real Keras: both sides are readings of the same published rule."""
+    import shutil
+    import subprocess
+    from cfd_amd import h5, keras_api as K
+    py = next((p for p in ("/opt/conda/bin/python3.9", shutil.which("python3.9") or "") if p and os.path.exists(p)), None)
+    if not h5.available() or not py or subprocess.run([py, "-c", "import h5py, numpy"], capture_output=True).returncode:
+        pytest.skip("no HDF5 C library / no interpreter with h5py in this image")
+    monkeypatch.setenv("CFD_AMD_DTYPE", "fp32")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_keras_archive.py")
+    H, W = 16, 64
+    # ---- DeltaP CNN: variable id -> our tensor, in the order DeltaP/models/generator.py:23-46 creates the layers
+    r = subprocess.run([py, script, "cnn", str(tmp_path / "cnn.keras"), str(H), str(W)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cnn_vars = ["g1.kernel", "g1.bias", "g3.kernel", "g3.bias", "g4.kernel", "g4.bias", "g6.kernel", "g6.bias",
+                "fc1.kernel", "fc1.bias", "fc2.kernel", "fc2.bias", "fc3.kernel", "fc3.bias"]
+    m = K.load_model(str(tmp_path / "cnn.keras"))
+    assert isinstance(m, K.CnnModel) and m.image_shape == (H, W, 1)
+    w = m.get_weights_dict()
+    for vid, name in enumerate(cnn_vars):
+        assert np.array_equal(w[name], _golden_fill(vid, w[name].shape)), name
+    opt = m._tr().opt
+    assert opt.t == 5
+    names, mom, vel = K._opt_keras(m.net.params, opt)
+    assert names == cnn_vars                                     # Adam's slots follow trainable_variables
+    for vid, name in enumerate(cnn_vars):
+        assert np.array_equal(mom[name], _golden_fill(1000 + vid, mom[name].shape)), name
+        assert np.array_equal(vel[name], _golden_fill(2000 + vid, vel[name].shape, True)), name
+    x = np.random.default_rng(0).standard_normal((2, H, W, 1)).astype("float32")
+    assert np.isfinite(m.predict(x)).all() and np.isfinite(m.train_on_batch(x, np.zeros((2, 1), "float32")))
+    # ---- discriminator, compiled before define_gan froze anything: Adam over kernels, biases, gamma, beta
+    r = subprocess.run([py, script, "disc", str(tmp_path / "d.keras"), str(H), str(W)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    disc_vars = ["c1.kernel", "c1.bias",
+                 "c2.kernel", "c2.bias", "c2.bn.gamma", "c2.bn.beta", "c2.bn.moving_mean", "c2.bn.moving_var",
+                 "c3.kernel", "c3.bias", "c3.bn.gamma", "c3.bn.beta", "c3.bn.moving_mean", "c3.bn.moving_var",
+                 "c4.kernel", "c4.bias", "c4.bn.gamma", "c4.bn.beta", "c4.bn.moving_mean", "c4.bn.moving_var",
+                 "c5.kernel", "c5.bias", "c5.bn.gamma", "c5.bn.beta", "c5.bn.moving_mean", "c5.bn.moving_var",
+                 "c6.kernel", "c6.bias"]
+    d = K.load_model(str(tmp_path / "d.keras"))
+    assert isinstance(d, K.DiscriminatorModel) and d._d_freeze == "compile"
+    wd = d.get_weights_dict()
+    assert set(wd) == set(disc_vars)
+    for vid, name in enumerate(disc_vars):
+        assert np.array_equal(wd[name], _golden_fill(vid, wd[name].shape, name.endswith("moving_var"))), name
+    optd = d._tr().opt
+    assert optd.t == 3
+    names, mom, vel = K._opt_keras(d.net.params, optd)
+    trainable = [n for n in disc_vars if "moving" not in n]
+    assert names == trainable
+    for name in trainable:
+        vid = disc_vars.index(name)
+        assert np.array_equal(mom[name], _golden_fill(1000 + vid, mom[name].shape)), name
+        assert np.array_equal(vel[name], _golden_fill(2000 + vid, vel[name].shape, True)), name
 
 
 def test_load_model_reads_keras3_archives(tmp_path, monkeypatch):

@@ -29,8 +29,10 @@ class _FakeParams:
 
     def __init__(self, seed, bf16=True):
         g = torch.Generator().manual_seed(seed)
-        self.n_main, self.n_trainable, self.n_total = 7 * 1024, 7 * 1024 + 512, 8 * 1024
-        self.specs = {"e1.kernel": _Spec(0), "e2.kernel": _Spec(512), "d1.kernel": _Spec(3 * 1024), "out.kernel": _Spec(6 * 1024)}
+        # ParamStore's layout: GEMM kernels in layer order | fp32-read tensors (first-layer kernel, biases) | BN | stats
+        self.n_kernels, self.n_main, self.n_trainable, self.n_total = 6 * 1024, 7 * 1024, 7 * 1024 + 512, 8 * 1024
+        self.specs = {"e2.kernel": _Spec(0), "d1.kernel": _Spec(2560), "out.kernel": _Spec(5632), "e1.kernel": _Spec(6 * 1024)}
+        self._pending_updates = []
         self.master = torch.randn(self.n_total, generator=g)
         self.compute = self.master[:self.n_trainable].to(torch.bfloat16) if bf16 else self.master
         self.grad = torch.zeros(self.n_trainable)
@@ -41,6 +43,9 @@ class _FakeParams:
             self.compute.copy_(self.master[:self.n_trainable])
 
     def refresh_transposed(self):
+        pass
+
+    def join_updates(self):
         pass
 
 
@@ -68,11 +73,9 @@ def _run_steps(rank, world, shard, bf16, grad_bf16=False, steps=3):
         for layer in ("out", "d1", "e2", "e1"):
             bk.ready(layer)
         bk.finish()
-        dp.wait()
-        segs = dp.take(P, opt.lo, opt.hi)
-        opt.step(dp.grad_scale, segs)
-        dp.gather_params(P, segs)
+        dp.apply(P, opt)             # per range: wait, Adam (own chunk | whole range), all-gather of the compute copy
     compute_after = P.compute.clone()
+    visible_after = P.master[P.n_kernels:P.n_trainable].clone()      # what forward / backward kernels read in fp32
     stale = None
     if shard and bf16:
         a, b = sorted(dp.partition[id(P)])[0]
@@ -80,7 +83,7 @@ def _run_steps(rank, world, shard, bf16, grad_bf16=False, steps=3):
         other = a if ca != a else cb                                # an element another rank owns
         stale = P.master[other].item()
     dp.sync_state(P, [opt])
-    return P, opt, dp, compute_after, stale
+    return P, opt, dp, (compute_after, visible_after), stale
 
 
 def _sharded_step_equals_replicated(rank, world):
@@ -93,12 +96,18 @@ def _sharded_step_equals_replicated(rank, world):
         Ps, opts_, dps, cs, stale = _run_steps(rank, world, True, bf16)
         sharded = {(a, b) for a, b in dps.partition[id(Ps)]}
         ok = ok and len(sharded) >= 2 and not dpr.partition            # the sharded form really ran (and only there)
-        ok = ok and torch.equal(cr, cs)
+        ok = ok and all(b <= Ps.n_kernels for _a, b in sharded)         # ... and only on the GEMM-kernel range
+        # BEFORE sync_state: the compute copy and every tensor the kernels read in fp32 from the master (first-layer
+        # kernel, biases, BatchNorm gamma / beta) equal the replicated step's -- and are the same on every rank
+        ok = ok and torch.equal(cr[0], cs[0]) and torch.equal(cr[1], cs[1])
+        for t in cs:
+            other = t.clone()
+            dist.broadcast(other, src=0)
+            ok = ok and torch.equal(other, t)
         ok = ok and torch.equal(Pr.master, Ps.master) and torch.equal(optr.m, opts_.m) and torch.equal(optr.v, opts_.v)
         ok = ok and optr.t == opts_.t == 3
         # rank 0's initial weights reached everyone: every rank's result equals rank 0's
         ref = Ps.master.clone()
-        import torch.distributed as dist
         dist.broadcast(ref, src=0)
         ok = ok and torch.equal(ref, Ps.master)
         if bf16:      # before sync_state, a chunk another rank owns held the stale master (that is what sync repairs)
@@ -122,8 +131,8 @@ def _worker(rank, world, port, out):
     from cfd_amd import trainer, sharding
     dp = trainer._DP(bucket_elems=1000, shard=False)            # several buckets, replicated form
     g = torch.arange(4096, dtype=torch.float32) * (rank + 1)
-    dp.reduce_async(g)
-    dp.wait()
+    for h in dp.reduce_async(g):
+        h.wait()
     expect = torch.arange(4096, dtype=torch.float32) * sum(r + 1 for r in range(world))
     ok = torch.equal(g, expect) and abs(dp.grad_scale - 1.0 / world) < 1e-12
     # backward-overlap buckets: ranges handed over tail first, disjoint, covering the trainable prefix exactly once

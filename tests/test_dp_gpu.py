@@ -148,6 +148,52 @@ def test_dp_world2_equals_one_process_on_both_samples(shard):
         assert torch.equal(ranks[0][k].params.master, ranks[1][k].params.master), name
 
 
+def test_dp_sharded_bf16_replicas_stay_coherent():
+    """bf16, sharded (the default for world 2 / 4 / 8): the all-gather redistributes only the bf16 compute copy, so the
+    fp32 master of the chunks a rank does not own is stale until sync_state().  Every tensor a forward or backward reads
+    in fp32 from the master (first-layer kernels, biases, BatchNorm gamma / beta) must therefore live OUTSIDE the sharded
+    range: after two steps and BEFORE any sync_state, both ranks hold the same compute copy and the same fp32-read
+    tensors bit for bit, and predict the same field."""
+    from cfd_amd import synthetic
+    xs, us, _ = synthetic.model_batch([0, 1])
+    xs, us = torch.from_numpy(xs).cuda(), torch.from_numpy(us).cuda()
+    vw = VirtualWorld(2)
+    ranks = [_make(vw, r, True, torch.bfloat16) for r in range(2)]
+    errors = []
+
+    def run(rank):
+        vw.local.rank = rank
+        vw.run_lock.acquire()
+        try:
+            for _ in range(2):
+                _step(*ranks[rank], xs[rank:rank + 1], us[rank:rank + 1], sample0=rank)
+        except BaseException as e:      # noqa: BLE001 -- reported by the main thread
+            errors.append((rank, repr(e)))
+            vw.barrier.abort()
+        finally:
+            if vw.run_lock.locked():
+                vw.run_lock.release()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    assert "reduce_scatter" in {k for k, _n in vw.calls[0]} and "all_gather" in {k for k, _n in vw.calls[0]}
+    for k, first in ((0, "e1"), (1, "c1")):
+        P0, P1 = ranks[0][k].params, ranks[1][k].params
+        assert P0.n_kernels >= (1 << 20) and P0.specs[first + ".kernel"].offset >= P0.n_kernels
+        assert torch.equal(P0.compute, P1.compute), k
+        assert torch.equal(P0.master[P0.n_kernels:P0.n_trainable], P1.master[P1.n_kernels:P1.n_trainable]), k
+        assert torch.equal(P0.m(first + ".kernel"), P1.m(first + ".kernel")) and torch.equal(P0.m(first + ".bias"), P1.m(first + ".bias"))
+        # the sharded range's master DID diverge (that is what sync_state repairs) -- the test would be vacuous otherwise
+        assert not torch.equal(P0.master[:P0.n_kernels], P1.master[:P1.n_kernels]), k
+    y0 = ranks[0][0].forward(xs[:1], seed=9, sample0=0).float()
+    y1 = ranks[1][0].forward(xs[:1], seed=9, sample0=0).float()
+    assert float((y0 - y1).abs().max()) <= 1e-5 * float(y0.abs().max()) + 1e-7      # (fp32 atomics order of the BN statistics)
+
+
 def test_bench_starts_two_nccl_ranks_by_itself():
     """`python bench.py --gpus 2` (no launcher): two child ranks over RCCL, the sharded data-parallel training step,
     one JSON line from rank 0 with n_gpus = 2.  Needs two GPUs: RCCL refuses two ranks on one device, so this skips on

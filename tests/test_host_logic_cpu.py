@@ -297,3 +297,61 @@ def test_eval_plans_select_and_scale_like_the_six_reference_scripts():
     assert cli.EVAL_PLANS[("P", "valid")]["folder"] == "./100_case_si_test/processed/"
     assert cli.EVAL_PLANS[("DeltaP", "valid")]["folder"] == "./130_case/processed/"
     assert cli.EVAL_PLANS[("U", "test")]["folder"] == "./30_case_duyanh/processed/"
+
+
+# ---- bench.py: what it did not measure is named, and a failure or hang is never a green run -------------------------
+def _bench_dry(extra_env, timeout=120):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CFD_BENCH_DRY="1", **extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                          text=True, timeout=timeout, cwd=root)
+
+
+def _last_json_line(text):
+    import json
+    return json.loads([l for l in text.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_extras_error_under_two_ranks_exits_nonzero():
+    """WORLD_SIZE = 2 (gloo, CFD_BENCH_DRY: canned workloads, one collective each): an extra workload that raises is
+    recorded in the line AND the run exits non-zero; the spawner stops the other rank and relays the code"""
+    r = _bench_dry({"CFD_BENCH_FAIL_EXTRA": "train_u_bf16"})
+    assert r.returncode == 4, (r.returncode, r.stderr[-800:])
+    line = _last_json_line(r.stdout)
+    assert "forced by CFD_BENCH_FAIL_EXTRA" in line["also"]["train_u_bf16"]["error"]
+    assert "infer_all_bf16" in line["also"] and "resample" not in line["also"]      # measured before / never started
+    assert "train_u_bf16" in r.stderr
+
+
+def test_bench_hang_in_a_collective_exits_nonzero_and_names_the_workload():
+    """one rank never reaches an extra's collective: the watchdog prints what was measured, names the workload in
+    flight and leaves with code 3 (it used to leave with 0)"""
+    r = _bench_dry({"CFD_BENCH_HANG_EXTRA": "train_deltap_bf16", "CFD_BENCH_WATCHDOG_S": "4"})
+    assert r.returncode == 3, (r.returncode, r.stderr[-800:])
+    line = _last_json_line(r.stdout)
+    assert "train_deltap_bf16" in line["watchdog"] and "exit code 3" in line["watchdog"]
+    assert "train_u_fp32_b1" in line["also"] and "train_deltap_bf16" not in line["also"]
+
+
+def test_bench_green_run_two_ranks_exits_zero_and_has_configs0_key():
+    r = _bench_dry({})
+    assert r.returncode == 0, r.stderr[-800:]
+    line = _last_json_line(r.stdout)
+    assert line["n_gpus"] == 2 and set(line["also"]) == {"infer_all_bf16", "train_u_bf16", "train_u_bf16_b32",
+                                                         "train_u_fp32_b1", "train_deltap_bf16", "resample"}
+
+
+def test_bench_names_the_profile_its_pmc_figures_come_from():
+    """roofline.traffic / mfma_busy_frac_pmc are read from a committed profile, not measured in the run: the line says
+    which file, which commit and whether the kernel sources are the ones running"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    traffic, busy, src = bench.pmc_traffic("infer_all_bf16")
+    assert traffic and src and src["file"].startswith("profiles/") and src["file"].endswith("_infer_all_bf16_summary.json")
+    assert {"git_head", "csrc_sha16", "same_sources_as_this_run", "note"} <= set(src)
+    assert "not measured in this run" in src["note"]
+    tr, rsrc = bench.pmc_traffic_resample()
+    assert tr and rsrc["file"].endswith("_resample_summary.json")
+    assert len(bench.csrc_sha16()) == 16
