@@ -61,7 +61,8 @@ static void fastdiv_make(unsigned d, unsigned (&c)[3]) {
 // igemm256h.hip: patch-staged variant (bf16, 3x3 stride 1 and the transposed 4x4 stride 2, no split-K).  `p` as prepared
 // by igemm256_launch (mtiles / ntiles / nblocks for 256-row m tiles and `ntile`-wide n tiles).
 bool igemm256h_eligible(const IgemmParams &p, int dtype, int ntile);
+// coresident: the 128(n) x 256(m) kernel with 32-channel K tiles, two workgroups per CU (ntile must be 128)
 int igemm256h_launch(const IgemmParams &p, int ntile, unsigned xbytes, unsigned wbytes, int cls_fast, int stage_out,
-                     hipStream_t st);
+                     hipStream_t st, bool coresident = false);
 
 }  // namespace cfd

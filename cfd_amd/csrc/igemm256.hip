@@ -1185,7 +1185,13 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   P.g = pin;
   IgemmParams &p = P.g;
   p.mtiles = cdiv(p.M, 256);
-  const int ntile = igemm256_ntile(p);
+  int ntile = igemm256_ntile(p);
+  // CFD_TUNE_PATCH: 2 = the co-resident patch kernel (two workgroups per CU, igemm256h.hip) for the layers that take
+  // 128-wide n tiles anyway, 3 = for every patch-eligible layer (a 256-wide layer then runs as two 128-wide n tiles)
+  const int pmode = tuning(CFD_TUNE_PATCH);
+  const bool cores = pmode >= 2 && tuning(CFD_TUNE_IGEMM256_PD) < 0 && !p.pool && (pmode == 3 || ntile == 128) &&
+                     igemm256h_eligible(p, dtype, 128);
+  if (cores) ntile = 128;
   p.ntiles = p.Cout / ntile;
   p.nblocks = p.mtiles * p.ntiles * p.nclass * p.split_k;
   P.xbytes = (unsigned)x_bytes(p, es);
@@ -1232,7 +1238,7 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   const int pdt = tuning(CFD_TUNE_IGEMM256_PD);
   // stride-1 tap grids on whole 8 x 32 pixel tiles: the activation operand is staged once per channel chunk (igemm256h.hip)
   if (pdt < 0 && igemm256h_eligible(p, dtype, ntile))
-    return igemm256h_launch(p, ntile, P.xbytes, P.wbytes, P.cls_fast, P.stage_out, st);
+    return igemm256h_launch(p, ntile, P.xbytes, P.wbytes, P.cls_fast, P.stage_out, st, cores);
   // persistent form (igemm256p_kernel): bf16, 256-wide n tiles, more tiles than CUs, every K range even
   // (CFD_TUNE_IGEMM256_PD: 36 forces it where legal, 26 forbids it)
   const int ktiles_all = p.ntaps * p.cpt;

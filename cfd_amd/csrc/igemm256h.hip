@@ -709,6 +709,274 @@ __global__ __launch_bounds__(512, 2) void igemm128nh_kernel(IgemmHaloParams P) {
   if (p.out_bf16) direct_epi(IC<1>{}); else direct_epi(IC<2>{});
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 128(n) x 256(m) CO-RESIDENT variant (round 3): the same patch-staged tile with a K tile of ONE TAP x 32 CHANNELS, sized so
+// that TWO workgroups share a CU (69 KiB of LDS, <= 128 registers per lane).
+//
+// Why: one 135-150 KiB workgroup per CU leaves nothing to run under a tile's set-up, cold first loads, epilogue and store
+// drain (~7 K tiles' worth per tile, stamp build: 10 % of a 64-K-tile layer, 40 % of P d5's tiles, 64 % of DeltaP g3's), and
+// inside the K loop each SIMD holds exactly two waves, so a barrier turn-around (~190 cycles against a 512-cycle MFMA
+// cluster) is dead time on the matrix pipe.  With two workgroups per CU every SIMD holds four waves from two independent
+// barrier domains: one workgroup's epilogue runs under the other's K loop, and a wave may spend three quarters of its
+// time outside its MFMA cluster before the pipe idles.
+//
+// What had to shrink: the 64-channel patch double-buffered is 86 KiB.  Here a chunk is 32 channels (patch 22 KiB per stage)
+// and a K tile is one tap of it: weights 128 rows x 64 B = 8 KiB per stage in a three-stage ring, ONE k-step of 16 MFMAs per
+// wave and K tile (fragments: 4 + 4 registers quads instead of 8 + 8).  Rows are 64 B (one pixel / one weight row of 32
+// channels); their four 16-B chunks are XOR-ed with bits 1-2 of the row index (chunk ^ ((row >> 1) & 3)), which makes
+// ds_read_b128 conflict-free for 16 consecutive rows at ANY starting row (tap shifts are odd as often as even; searched by
+// brute force over the instruction's lane groups) and is invariant under +16 rows, so fragments sit at immediate offsets.
+// A wave-level LDS-DMA piece = 1 KiB = 16 rows; lane -> row lane >> 2, physical chunk lane & 3.
+//   phase k: read stage k % 3 and the patch; issue [patch load n_t <= 1] + A(k+2) into stage (k+2) % 3; vmcnt(1 + n_t)
+//   (A(k+1) landed; the chunk's last K tile carries no patch load, so the whole next patch has landed too); barrier;
+//   16 MFMAs; barrier.  The two wave groups run one barrier apart as in the other kernels.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int C_ST = 128 * 64;          // one weight stage
+constexpr int C_ABYTES = 3 * C_ST;
+
+template <int NT, bool S2 = false> struct HaloGeoC {
+  static constexpr int PH = H_TH + ((NT == 9 || S2) ? 2 : 1);
+  static constexpr int PP = PH * H_PW;             // patch pixels
+  static constexpr int NPI = (PP + 15) / 16;       // wave-level load instructions (16 pixels x 64 B = 1 KiB each)
+  static constexpr int PPW = (NPI + 7) / 8;        // ... per wave
+  static constexpr int PER = (PPW + NT - 2) / (NT - 1);
+  static constexpr int PATCH = NPI * 1024;
+  static constexpr int BIAS_OFF = C_ABYTES + 2 * PATCH;   // the n tile's bias (512 B; the load writes 1 KiB)
+  static constexpr int LDS = BIAS_OFF + 1024;
+  static constexpr int first(int t) { return t * PER < PPW ? t * PER : PPW; }
+  static constexpr int count(int t) { return first(t + 1) - first(t); }
+  static_assert(first(NT - 1) == PPW, "the last K tile of a chunk must not carry patch loads");
+  static_assert(PER <= 1, "vmcnt bookkeeping below assumes at most one patch load per K tile");
+  static_assert(2 * LDS <= 160 * 1024, "two workgroups must fit one CU");
+};
+
+template <int N> __device__ __forceinline__ void hwaitc() {
+  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else static_assert(N < 0, "unsupported vmcnt");
+}
+
+template <bool S2>
+__device__ __forceinline__ HaloChunk halo_chunk_c(int g, int c, int cin2, int wi, int ldx2) {   // 32-channel chunks: 64 B
+  if constexpr (S2) {
+    const int r = g >> 1, s = g & 1;
+    return {c * 64 - (r * 4 + s) * cin2, -(r * H_PW + s), (r * wi + s) * ldx2 + c * 64};
+  } else {
+    return {c * 64, 0, c * 64};
+  }
+}
+
+template <int NT, bool S2 = false>
+__global__ __launch_bounds__(512, 4) void igemm128c_kernel(IgemmHaloParams P) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  using G = HaloGeoC<NT, S2>;
+  const IgemmParams &p = P.g;
+  typedef bf16x8 frag_t;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const HaloTile tile = halo_tile(P);
+  const int cls = tile.cls, ph = cls >> 1, pw = cls & 1;
+  const int n0 = tile.nt * 128;
+  const int b = tile.b, ty0 = tile.ty0, tx0 = tile.tx0;
+  const int cpt = p.cpt;                                    // chunks of 32 channels per group (host: Cin / 32)
+  const int ncc = S2 ? 4 * cpt : cpt;
+  const int cin2 = p.Cin * 2, ldx2 = p.ldx * 2;
+  int ng = 0, nc = 0;
+  auto chunk_step = [&]() {                                 // (clamped at the last chunk: the stream's overrun re-reads it)
+    if (nc + 1 < cpt) ++nc;
+    else if (S2 && ng < 3) { nc = 0; ++ng; }
+  };
+  HaloChunk cur = halo_chunk_c<S2>(0, 0, cin2, p.Wi, ldx2);
+  chunk_step();
+  HaloChunk nxt = halo_chunk_c<S2>(ng, nc, cin2, p.Wi, ldx2);
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)P.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)P.wbytes, 0x00020000);
+
+  int toff[NT], wto[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    toff[t] = __builtin_amdgcn_readfirstlane(P.toff[cls][t]);
+    wto[t] = __builtin_amdgcn_readfirstlane(P.wtoff[cls][t]);
+  }
+
+  // ---- staging geometry: piece = 16 rows x 64 B; lane -> row lane >> 2, physical chunk lane & 3 = logical chunk ^ ((row >> 1) & 3)
+  const int lrow = lane >> 2;
+  const int kc = (lane & 3) ^ ((lrow >> 1) & 3);
+  const unsigned avoff = (unsigned)(((n0 + wave * 16 + lrow) * p.Kw + kc * 8) * 2);
+  unsigned pvoff[G::PPW];
+  {
+    const int py0 = ty0 + P.dymin[cls], px0 = tx0 + P.dxmin[cls];
+#pragma unroll
+    for (int j = 0; j < G::PPW; ++j) {
+      const int q = min(j * 8 + wave, G::NPI - 1);
+      const int pp = q * 16 + lrow;
+      const int py = pp / H_PW, px = pp - py * H_PW;
+      const int y = py0 + py, x = px0 + px;
+      constexpr int S = S2 ? 2 : 1;
+      const bool ok = pp < G::PP && (unsigned)y < (unsigned)p.Hq && (unsigned)x < (unsigned)p.Wq;
+      pvoff[j] = ok ? (unsigned)((((b * p.Hi + S * y) * p.Wi + S * x) * p.ldx + kc * 8) * 2) : OOB;
+    }
+  }
+
+  char *const ldsw = lds + wave * 1024;
+  auto issueA = [&](int st, unsigned sa) { bload16(wrs, avoff, sa, ldsw + st * C_ST); };
+  auto issueP = [&](int j, int pst, unsigned sp) {
+    const int q = min(j * 8 + wave, G::NPI - 1);
+    bload16(xrs, pvoff[j], sp, lds + C_ABYTES + pst * G::PATCH + q * 1024);
+  };
+
+  // ---- fragment read offsets (row r of a stage / pixel pp of the patch at r * 64, chunk fq at (fq ^ ((r >> 1) & 3)) * 16)
+  const int fr = lane & 15, fq = lane >> 4;
+  const char *const ard = lds + wr * 64 * 64 + fr * 64 + ((fq ^ ((fr >> 1) & 3)) << 4);
+  const int L0 = 2 * wc * H_PW + fr;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (p.bias) {   // the n tile's bias rides to LDS with the first loads (lanes 32-63 fetch the next tile's or zeros: unused)
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, p.Cout * 4, 0x00020000);
+    bload16(brs, (unsigned)(n0 * 4 + lane * 16), 0u, lds + G::BIAS_OFF);
+  }
+#pragma unroll
+  for (int j = 0; j < G::PPW; ++j) issueP(j, 0, (unsigned)cur.p);
+  issueA(0, (unsigned)(wto[0] + cur.a));
+  issueA(1, (unsigned)(wto[1 % NT] + (1 / NT ? nxt.a : cur.a)));
+  hwaitc<1>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+
+  frag_t a[4], bf[4];
+  int stg = 0;   // ring stage of the current K tile
+
+  auto ktile = [&](auto tc, int c) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int NP = G::count(t), J0 = G::first(t);
+    constexpr int t2 = (t + 2) % NT, k2 = (t + 2) / NT;
+    int st;
+    if constexpr (NT % 3 == 0) st = t % 3; else st = stg;
+    const int st2 = st == 0 ? 2 : st - 1;   // (st + 2) % 3
+    const int pst = c & 1;
+    const unsigned sa2 = (unsigned)(wto[t2] + (k2 ? nxt.a : cur.a));
+    const unsigned sp = (unsigned)nxt.p;
+    // (opaque: without a group shift the tap's lane addresses are loop-invariant, and hoisting nine taps' worth of them
+    //  out of the chunk loop spills -- scratch reloads count in vmcnt and would break the counted waits)
+    int pp0 = L0 + toff[t] + cur.t;
+    asm volatile("" : "+v"(pp0));
+    const int pp1 = pp0 + H_PW;
+    const int pb = C_ABYTES + pst * G::PATCH;
+    const char *b0p = lds + pb + (pp0 << 6) + ((fq ^ ((pp0 >> 1) & 3)) << 4);
+    const char *b1p = lds + pb + (pp1 << 6) + ((fq ^ ((pp1 >> 1) & 3)) << 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *(const frag_t *)(ard + st * C_ST + i * 1024);
+    bf[0] = *(const frag_t *)(b0p);
+    bf[1] = *(const frag_t *)(b0p + 1024);
+    bf[2] = *(const frag_t *)(b1p);
+    bf[3] = *(const frag_t *)(b1p + 1024);
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) issueP(J0 + jj, pst ^ 1, sp);
+    issueA(st2, sa2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    hwaitc<1 + NP>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mma(a[i], bf[j], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if constexpr (NT % 3 != 0) stg = stg == 2 ? 0 : stg + 1;
+  };
+
+  for (int c = 0; c < ncc; ++c) {
+    ktile(IC<0>{}, c); ktile(IC<1>{}, c); ktile(IC<2>{}, c); ktile(IC<3>{}, c);
+    if constexpr (NT == 9) {
+      ktile(IC<4>{}, c); ktile(IC<5>{}, c); ktile(IC<6>{}, c); ktile(IC<7>{}, c); ktile(IC<8>{}, c);
+    }
+    cur = nxt;
+    chunk_step();
+    nxt = halo_chunk_c<S2>(ng, nc, cin2, p.Wi, ldx2);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  hwait<0>();   // the tail loads must not outlive the workgroup's LDS allocation
+
+  if (p.stat_sum) {   // fused BatchNorm statistics, as in igemm128nh_kernel
+    __syncthreads();
+    float *part = (float *)lds;   // [2][4 wc][128 n]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nl = wr * 64 + i * 16 + fq * 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *(const f32x4 *)(lds + G::BIAS_OFF + nl * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[i][j][r] + bv[r];
+          t1 += v;
+          t2 = fmaf(v, v, t2);
+        }
+        t1 = row16_sum(t1);
+        t2 = row16_sum(t2);
+        if (fr == 0) {
+          part[(0 * 4 + wc) * 128 + nl + r] = t1;
+          part[(1 * 4 + wc) * 128 + nl + r] = t2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int which = tid >> 7, c = tid & 127;
+      const float *pp = part + which * 512 + c;
+      const float tot = pp[0] + pp[128] + pp[256] + pp[384];
+      atomicAdd((which ? p.stat_sq : p.stat_sum) + (size_t)b * p.Cout + n0 + c, tot);
+    }
+  }
+
+  const float act_ns = act_neg_scale(p.act, p.slope);
+  const bool act_sig = p.act == CFD_ACT_SIGMOID;
+  auto direct_epi = [&](auto mode_c) {
+    constexpr int MODE = decltype(mode_c)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int local = wc * 64 + j * 16 + fr;
+      const int qy = ty0 + (local >> 5), qx = tx0 + (local & 31);
+      const int64_t opix = p.kind == CFD_CONVT_K4S2 ? ((int64_t)b * p.Ho + 2 * qy + ph) * p.Wo + 2 * qx + pw
+                                                     : ((int64_t)b * p.Hq + qy) * p.Wq + qx;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wr * 64 + i * 16 + fq * 4;
+        f32x4 v = acc[i][j];
+        if (p.bias) v += *(const f32x4 *)(lds + G::BIAS_OFF + (n - n0) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act_linear(v[r], act_ns);
+        if (act_sig) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + __expf(-v[r]));
+        }
+        if constexpr (MODE == 1) {
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4 *)(p.y + (opix * p.ldy + n) * 2) = o;
+        } else {
+          *(f32x4 *)(p.y + (opix * p.ldy + n) * 4) = v;
+        }
+      }
+    }
+  };
+  if (p.out_bf16) direct_epi(IC<1>{}); else direct_epi(IC<2>{});
+}
+
 // which layers take this path: bf16, a stride-1 tap grid (3x3 'same' conv, one sub-pixel class of the transposed 4x4
 // stride-2 conv, or one input parity of the 4x4 stride-2 conv), whole n tiles, no split-K, a class grid that 8 x 32 tiles
 // cover exactly
@@ -721,10 +989,14 @@ bool igemm256h_eligible(const IgemmParams &p, int dtype, int ntile) {
 }
 
 int igemm256h_launch(const IgemmParams &pin, int ntile, unsigned xbytes, unsigned wbytes, int cls_fast, int stage_out,
-                     hipStream_t st) {
+                     hipStream_t st, bool coresident) {
   IgemmHaloParams P;
   memset(&P, 0, sizeof(P));
   P.g = pin;
+  if (coresident) {
+    CFD_REQUIRE(ntile == 128 && !pin.pool && pin.Cin % 32 == 0, "co-resident patch kernel: 128-wide n tiles, no pooled epilogue");
+    P.g.cpt = pin.Cin / 32;      // this kernel's chunks are 32 channels
+  }
   const IgemmParams &p = P.g;
   CFD_REQUIRE((ntile == 128 || ntile == 256) && igemm256h_eligible(p, CFD_BF16, ntile) && p.ntiles * ntile == p.Cout,
               "patch-staged kernel: shape not eligible");
@@ -769,7 +1041,12 @@ int igemm256h_launch(const IgemmParams &pin, int ntile, unsigned xbytes, unsigne
   } while (0)
   typedef HaloGeo<4, true> GeoS2;
   typedef HaloGeo3<4, true> Geo3S2;
-  if (ntile == 256) {
+  typedef HaloGeoC<4, true> GeoCS2;
+  if (coresident) {
+    if (s2) CFD_LAUNCH_H((igemm128c_kernel<4, true>), GeoCS2);
+    else if (p.ntaps == 9) CFD_LAUNCH_H(igemm128c_kernel<9>, HaloGeoC<9>);
+    else CFD_LAUNCH_H(igemm128c_kernel<4>, HaloGeoC<4>);
+  } else if (ntile == 256) {
     if (s2) CFD_LAUNCH_H((igemm256h_kernel<4, true>), GeoS2);
     else if (p.ntaps == 9) CFD_LAUNCH_H(igemm256h_kernel<9>, HaloGeo<9>);
     else CFD_LAUNCH_H(igemm256h_kernel<4>, HaloGeo<4>);

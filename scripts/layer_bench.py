@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--ntile", type=int, default=-1, help="-1 heuristic, 128 / 256: n tile of the ping-pong kernels")
     ap.add_argument("--only", default="", help="comma list of layer names, e.g. e2,d4")
     ap.add_argument("--bias", type=int, default=0, help="1: forward launches add a bias vector (as the nets do)")
+    ap.add_argument("--patch", default="-1", help="comma list of CFD_TUNE_PATCH values timed side by side per layer "
+                                                   "(-1/1 patch kernels, 0 off, 2 co-resident for 128-wide, 3 co-resident everywhere)")
     args = ap.parse_args()
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     ops.set_tuning(ops.TUNE_IGEMM256, args.igemm256)
@@ -111,12 +113,18 @@ def main():
             fns = {"fwd": lambda: ops.conv_forward(x, wt, bias, kind, cout, out=y),
                    "dgrad": lambda: ops.conv_forward(dy, wtt, None, bk, cin, out=dx),
                    "wgrad": lambda: ops.conv_wgrad(x, dy, kind, cout, dw)}
+            patches = [int(v) for v in args.patch.split(",")]
             for m in modes:
-                us = timeit(fns[m], args.iters)
-                tf = flops / us / 1e6
-                tot[m][0] += flops; tot[m][1] += us
-                print(f"{net:6s} {name:4s} {m:5s} B={B} in=({h},{w},{cin}) cout={cout} GFLOP={flops/1e9:8.2f} "
-                      f"{us:9.1f} us {tf:8.1f} TF {tf/PEAK[args.dtype]:.3f}", flush=True)
+                for pm in patches:
+                    ops.set_tuning(ops.TUNE_PATCH, pm)
+                    us = timeit(fns[m], args.iters)
+                    tf = flops / us / 1e6
+                    if pm == patches[0]:
+                        tot[m][0] += flops; tot[m][1] += us
+                    tag = f" patch={pm}" if len(patches) > 1 else ""
+                    print(f"{net:6s} {name:4s} {m:5s} B={B} in=({h},{w},{cin}) cout={cout} GFLOP={flops/1e9:8.2f} "
+                          f"{us:9.1f} us {tf:8.1f} TF {tf/PEAK[args.dtype]:.3f}{tag}", flush=True)
+            ops.set_tuning(ops.TUNE_PATCH, -1)
     for m in modes:
         if tot[m][1] > 0:
             tf = tot[m][0] / tot[m][1] / 1e6

@@ -191,7 +191,9 @@ def test_dp_sharded_bf16_replicas_stay_coherent():
         assert not torch.equal(P0.master[:P0.n_kernels], P1.master[:P1.n_kernels]), k
     y0 = ranks[0][0].forward(xs[:1], seed=9, sample0=0).float()
     y1 = ranks[1][0].forward(xs[:1], seed=9, sample0=0).float()
-    assert float((y0 - y1).abs().max()) <= 1e-5 * float(y0.abs().max()) + 1e-7      # (fp32 atomics order of the BN statistics)
+    # same weights bit for bit; two forwards still differ by the commit order of the fp32 atomics that accumulate the
+    # BatchNorm statistics, which in bf16 moves an activation by one rounding step (2^-8 relative) here and there
+    assert float((y0 - y1).abs().max()) <= 1e-2 * float(y0.abs().max())
 
 
 def test_bench_starts_two_nccl_ranks_by_itself():

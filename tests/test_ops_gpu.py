@@ -206,6 +206,63 @@ def test_conv_forward_patch_staged(kind, B, H, W, cin, cout, ntile):
     assert relerr(a.cpu(), b.cpu()) <= 1e-5          # same products, another summation order (chunk-major K)
 
 
+@pytest.mark.parametrize("kind,B,H,W,cin,cout", [
+    ("k3s1", 2, 16, 32, 64, 256),       # two 32-channel chunks, two n tiles
+    ("k3s1", 1, 8, 64, 96, 128),        # three chunks (9 taps: the ring stage is t % 3, the patch stage flips per chunk)
+    ("k3s1", 3, 24, 96, 32, 256),       # ONE chunk: the patch of "chunk 1" is never read; grid that is no power of two
+    ("convT", 2, 8, 32, 128, 256),      # four sub-pixel classes, four chunks
+    ("convT", 1, 16, 64, 160, 384),     # five chunks (4 taps: the ring stage runs on across chunks), three n tiles
+    ("k4s2", 2, 16, 64, 64, 256),       # stride 2 = four input-parity groups; two chunks per group
+    ("k4s2", 1, 32, 128, 96, 128),      # three chunks per group, 2 x 2 tiles: every image border in its own tile
+    ("k4s2", 3, 16, 192, 32, 384),      # one chunk per group, three tiles per row
+])
+def test_conv_forward_patch_coresident(kind, B, H, W, cin, cout):
+    """igemm128c_kernel (round 3: the patch-staged 128(n) x 256(m) tile with 32-channel K tiles, two workgroups per CU;
+    cfd_set_tuning(CFD_TUNE_PATCH, 3) routes every patch-eligible layer to it) against the oracle (fp32 output, bf16
+    output + LeakyReLU into a channel slice), against the per-tap kernel, and reading a channel slice of a wider input"""
+    from cfd_amd import ops
+    dtype, dev = torch.bfloat16, "cuda"
+    ops.set_tuning(ops.TUNE_PATCH, 3)
+    try:
+        _igemm256_case(kind, B, H, W, cin, cout, 1, dtype, -1)
+    finally:
+        ops.set_tuning(ops.TUNE_PATCH, -1)
+    x = q(rnd((B, H, W, cin), 1), dtype)
+    bias = rnd((cout,), 3, 0.1)
+    if kind == "convT":
+        wk = q(rnd((4, 4, cout, cin), 2, 0.05), dtype)
+        wp, code = ops.pack_convT_weight(wk.to(dev), dtype), ops.CONVT_K4S2
+    elif kind == "k4s2":
+        wk = q(rnd((4, 4, cin, cout), 2, 0.05), dtype)
+        wp, code = ops.pack_conv_weight(wk.to(dev), dtype), ops.CONV_K4S2
+    else:
+        wk = q(rnd((3, 3, cin, cout), 2, 0.05), dtype)
+        wp, code = ops.pack_conv_weight(wk.to(dev), dtype), ops.CONV_K3S1
+    wide = torch.full((B, H, W, cin + 128), 3.0, dtype=dtype, device=dev)
+    wide[..., 64:64 + cin] = x.to(dev).to(dtype)
+    ops.set_tuning(ops.TUNE_IGEMM256, 1)
+    try:
+        ops.set_tuning(ops.TUNE_PATCH, 3)
+        a = ops.conv_forward(wide[..., 64:64 + cin], wp, bias.to(dev), code, cout, out_dtype=torch.float32, split_k=1)
+        # fused BatchNorm statistics from this kernel's epilogue (per sample, per channel; bias included)
+        stats = (torch.zeros((B, cout), device=dev), torch.zeros((B, cout), device=dev))
+        a2, fused = ops.conv_forward(x.to(dev).to(dtype), wp, bias.to(dev), code, cout, out_dtype=torch.float32, split_k=1,
+                                     stats=stats)
+        ops.set_tuning(ops.TUNE_PATCH, 0)
+        b = ops.conv_forward(x.to(dev).to(dtype), wp, bias.to(dev), code, cout, out_dtype=torch.float32, split_k=1)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning(ops.TUNE_IGEMM256, -1)
+        ops.set_tuning(ops.TUNE_PATCH, -1)
+    assert relerr(a.cpu(), b.cpu()) <= 1e-5          # same products, another summation order
+    assert not torch.equal(a, b) or cin == 32        # ... which also shows that the two launches ran different kernels
+    assert torch.equal(a, a2)
+    assert fused
+    n = a.shape[1] * a.shape[2]
+    assert relerr(stats[0].cpu() / n, b.float().mean(dim=(1, 2)).cpu()) <= 2e-5
+    assert relerr(stats[1].cpu() / n, (b.float() ** 2).mean(dim=(1, 2)).cpu()) <= 2e-5
+
+
 def _igemm256_case(kind, B, H, W, cin, cout, split_k, dtype, pd):
     """the 256x256 ping-pong kernel (igemm256.hip; bf16 and exact-f32 MFMA), forced on, against the oracle; bias +
     LeakyReLU fused, output written into a channel slice of a wider buffer"""
