@@ -72,6 +72,8 @@ SIGNATURES = {
                                _vp, _i, _i, _i, _f, _i, _i, _f, _i, _vp, _vp]),
     "cfd_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _i, _f, _i, _vp]),
     "cfd_maxpool2_act_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cfd_act_bwd_dbias": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _i, _f, _i, _vp, _vp]),
+    "cfd_maxpool2_act_bwd_dbias": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "cfd_dropout_apply": (_i, [_vp, _vp, _vp, _i64, _f, C.c_uint64, _i64, _i, _vp]),
     "cfd_bce_logits": (_i, [_vp, _vp, _f, _i64, _vp, _vp, _f, _vp]),
     "cfd_field_loss": (_i, [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp, _i, _vp]),

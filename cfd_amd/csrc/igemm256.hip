@@ -1186,11 +1186,17 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   IgemmParams &p = P.g;
   p.mtiles = cdiv(p.M, 256);
   int ntile = igemm256_ntile(p);
-  // CFD_TUNE_PATCH: 2 = the co-resident patch kernel (two workgroups per CU, igemm256h.hip) for the layers that take
-  // 128-wide n tiles anyway, 3 = for every patch-eligible layer (a 256-wide layer then runs as two 128-wide n tiles)
+  // CFD_TUNE_PATCH: 1 = patch kernels, never the co-resident one; 2 = the co-resident patch kernel (two workgroups per CU,
+  // igemm256h.hip) for every layer that takes 128-wide n tiles anyway; 3 = for every patch-eligible layer (a 256-wide layer
+  // then runs as two 128-wide n tiles); -1 = heuristic below
+  // Measured (scripts/layer_bench.py --patch=-1,2,3, B = 128, one box): the co-resident kernel's 64 x 64 wave tiles read
+  // 1.4 x the LDS bytes per FLOP of the 256-wide kernel's 128 x 64 ones and its K loop runs at 0.55 of the MFMA peak where
+  // igemm256h reaches 0.64 (U d5 1 378 -> 1 580 us, U d4 690 -> 794, DeltaP g4 487 -> 537); against igemm128nh it is even
+  // on long K loops (P d5 452.3 -> 451.8 us) and wins where the per-tile overhead dominates (DeltaP g3, 9 K tiles of 64
+  // channels: 215.9 -> 178.7 us).  Heuristic (-1): 128-wide layers with at most 16 such K tiles.
   const int pmode = tuning(CFD_TUNE_PATCH);
-  const bool cores = pmode >= 2 && tuning(CFD_TUNE_IGEMM256_PD) < 0 && !p.pool && (pmode == 3 || ntile == 128) &&
-                     igemm256h_eligible(p, dtype, 128);
+  const bool cores_want = pmode == 3 || (ntile == 128 && (pmode == 2 || (pmode < 0 && p.ntaps * (p.Cin / 64) <= 16)));
+  const bool cores = cores_want && tuning(CFD_TUNE_IGEMM256_PD) < 0 && !p.pool && igemm256h_eligible(p, dtype, 128);
   if (cores) ntile = 128;
   p.ntiles = p.Cout / ntile;
   p.nblocks = p.mtiles * p.ntiles * p.nclass * p.split_k;

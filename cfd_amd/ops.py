@@ -678,7 +678,14 @@ def bn_act_bwd(x, mean, var, gamma, beta, g1, act1, dx, dgamma, dbeta, g2=None, 
     return dx
 
 
-def act_bwd(y, g1, act1, dx, g2=None, act2=ACT_RELU, slope=LEAKY_SLOPE):
+def _dbias_ok(Cc: int) -> bool:
+    """can the backward kernels carry the bias-gradient reduction for this channel count? (C / 8 divides 256)"""
+    return Cc % 8 == 0 and Cc <= 2048 and 256 % (Cc // 8) == 0
+
+
+def act_bwd(y, g1, act1, dx, g2=None, act2=ACT_RELU, slope=LEAKY_SLOPE, dbias=None):
+    """dbias (fp32 (C,), accumulated into): the bias gradient of the layer whose pre-activation gradient is written,
+    taken in the same pass (else a colsum pass over dx follows for channel counts the fused form does not take)"""
     yp, ldy = _nhwc(y)
     g1p, ldg1 = _nhwc(g1)
     g2p, ldg2 = (None, 0) if g2 is None else _nhwc(g2)
@@ -688,18 +695,32 @@ def act_bwd(y, g1, act1, dx, g2=None, act2=ACT_RELU, slope=LEAKY_SLOPE):
     _need(tuple(g1.shape) == shp and tuple(dx.shape) == shp and (g2 is None or tuple(g2.shape) == shp),
           f"act_bwd: g1/g2/dx must have y's shape {shp}")
     _need(g1.dtype == y.dtype and dx.dtype == y.dtype and (g2 is None or g2.dtype == y.dtype), "act_bwd: one dtype")
+    if dbias is not None and _dbias_ok(Cc):
+        _numel(dbias, Cc, "act_bwd dbias", torch.float32)
+        check(_lib.load().cfd_act_bwd_dbias(yp, ldy, g1p, ldg1, g2p, ldg2, dxp, lddx, y.numel() // Cc, Cc, act1, act2, slope,
+                                            _DT[y.dtype], _ptr(dbias), _stream()), "cfd_act_bwd_dbias")
+        return dx
     check(_lib.load().cfd_act_bwd(yp, ldy, g1p, ldg1, g2p, ldg2, dxp, lddx, y.numel() // Cc, Cc, act1, act2, slope,
                                   _DT[y.dtype], _stream()), "cfd_act_bwd")
+    if dbias is not None:
+        colsum(dx, dbias)
     return dx
 
 
-def maxpool2_act_bwd(x, dy, dx, act, slope=LEAKY_SLOPE):
+def maxpool2_act_bwd(x, dy, dx, act, slope=LEAKY_SLOPE, dbias=None):
     B, H, W, Cc = x.shape
     _need(H % 2 == 0 and W % 2 == 0 and tuple(dy.shape) == (B, H // 2, W // 2, Cc) and tuple(dx.shape) == (B, H, W, Cc)
           and x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous() and dy.dtype == x.dtype
           and dx.dtype == x.dtype, "maxpool2_act_bwd: dy must be (B,H/2,W/2,C), dx (B,H,W,C), dense, x's dtype")
+    if dbias is not None and _dbias_ok(Cc):
+        _numel(dbias, Cc, "maxpool2_act_bwd dbias", torch.float32)
+        check(_lib.load().cfd_maxpool2_act_bwd_dbias(_ptr(x), _ptr(dy), _ptr(dx), B, H, W, Cc, act, slope, _DT[x.dtype],
+                                                     _ptr(dbias), _stream()), "cfd_maxpool2_act_bwd_dbias")
+        return dx
     check(_lib.load().cfd_maxpool2_act_bwd(_ptr(x), _ptr(dy), _ptr(dx), B, H, W, Cc, act, slope, _DT[x.dtype],
                                            _stream()), "cfd_maxpool2_act_bwd")
+    if dbias is not None:
+        colsum(dx, dbias)
     return dx
 
 

@@ -48,8 +48,11 @@ const char *cfd_last_error(void);
  *                         the same results; it trades distance evaluations per pixel against extra search rings)
  *   CFD_TUNE_NTILE        -1 heuristic | 128 | 256: n tile of the 256-row ping-pong kernels for layers whose Cout is a
  *                         multiple of 256 (128 = the 128(n) x 256(m) variant: twice the blocks, no split-K slabs)
- *   CFD_TUNE_PATCH        -1 / 1 on where legal | 0 off: bf16 3x3, 4x4 stride-2 and transposed-4x4 layers on whole 8 x 32 pixel
+ *   CFD_TUNE_PATCH        0 off | 1 on where legal: bf16 3x3, 4x4 stride-2 and transposed-4x4 layers on whole 8 x 32 pixel
  *                         tiles stage their activation operand once per 64-channel chunk as an input patch (igemm256h.hip)
+ *                         | 2: as 1, and every layer on 128-wide n tiles runs the CO-RESIDENT form (32-channel K tiles, 69 KiB
+ *                         of LDS, two workgroups per CU) | 3: every patch-eligible layer does | -1 (default): as 1, plus the
+ *                         co-resident form for 128-wide layers of at most 16 K tiles (per-tile overhead dominates there)
  */
 typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_WGRAD256 = 2, CFD_TUNE_CLASS_ORDER = 3,
                CFD_TUNE_STAGED_OUT = 4, CFD_TUNE_RESAMPLE_DENSITY = 5, CFD_TUNE_NTILE = 6, CFD_TUNE_PATCH = 7, CFD_TUNE_COUNT = 8 } cfd_tuning_key;
@@ -255,10 +258,19 @@ int cfd_bn_act_bwd_ws(const void *x, int ldx, int x_dtype, const float *mean, co
 /* layers without BN: dpre = g1*act1'(y) + g2*act2'(y), y = the saved activation (its sign decides) */
 int cfd_act_bwd(const void *y, int ldy, const void *g1, int ldg1, const void *g2, int ldg2, void *dx, int lddx,
                 int64_t pixels, int C, int act1, int act2, float leaky_slope, int dtype, void *stream);
+/* cfd_act_bwd that also accumulates (atomics; the caller zeroes it) the bias gradient of the layer whose pre-activation
+ * gradient it writes: dbias[c] += sum over pixels of dx[p][c], summed over the values as stored -- what a separate
+ * cfd_colsum pass over dx gives, without re-reading dx (Conv2D / Dense bias of the layers of
+ * DeltaP/models/generator.py:28-46 and the generators' bottleneck, U/models/generator.py:59-60).  C / 8 must divide 256. */
+int cfd_act_bwd_dbias(const void *y, int ldy, const void *g1, int ldg1, const void *g2, int ldg2, void *dx, int lddx,
+                      int64_t pixels, int C, int act1, int act2, float leaky_slope, int dtype, float *dbias, void *stream);
 /* MaxPooling2D(2,2) backward fused with the activation backward of the layer that fed the pool;
  * x = that layer's activation [B][Hi][Wi][C], dy = gradient of the pooled tensor, dx = gradient of its pre-activation */
 int cfd_maxpool2_act_bwd(const void *x, const void *dy, void *dx, int B, int Hi, int Wi, int C, int act,
                          float leaky_slope, int dtype, void *stream);
+/* the same, also accumulating that layer's bias gradient (see cfd_act_bwd_dbias) */
+int cfd_maxpool2_act_bwd_dbias(const void *x, const void *dy, void *dx, int B, int Hi, int Wi, int C, int act,
+                               float leaky_slope, int dtype, float *dbias, void *stream);
 /* Dropout(rate) on a dense tensor (fc1 output, DeltaP/models/generator.py:42) and on its gradient */
 int cfd_dropout_apply(const void *x, void *y, const uint8_t *mask, int64_t total, float rate, uint64_t seed,
                       int64_t elem0, int dtype, void *stream);

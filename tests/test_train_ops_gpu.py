@@ -348,3 +348,31 @@ def test_transpose_weight_exact(cout, kh, cin, flip, dtype):
         ref = ref.flip(1)
     ref = ref.permute(2, 1, 0).contiguous()
     assert torch.equal(wt.reshape(cin, kh * kh, cout), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 8, 12, 64), (8, 128, 128, 128), (3, 16, 24, 512), (5, 2, 2, 256)])
+def test_act_pool_bwd_with_bias_gradient(shape, dtype):
+    """cfd_act_bwd_dbias / cfd_maxpool2_act_bwd_dbias: the same dx as the plain kernels bit for bit, and the bias
+    gradient = column sums of dx AS STORED (what the separate cfd_colsum pass gave), accumulated into dbias"""
+    from cfd_amd import ops
+    dev = "cuda"
+    C = shape[-1]
+    y = q(O.leaky(rnd(shape, 1)), dtype).to(dev).to(dtype)
+    g1, g2 = q(rnd(shape, 2), dtype).to(dev).to(dtype), q(rnd(shape, 3), dtype).to(dev).to(dtype)
+    dx0, dx1 = torch.empty(shape, dtype=dtype, device=dev), torch.empty(shape, dtype=dtype, device=dev)
+    ops.act_bwd(y, g1, ops.ACT_LEAKY, dx0, g2=g2, act2=ops.ACT_RELU)
+    db = torch.full((C,), 0.5, dtype=torch.float32, device=dev)              # accumulated INTO
+    ops.act_bwd(y, g1, ops.ACT_LEAKY, dx1, g2=g2, act2=ops.ACT_RELU, dbias=db)
+    assert torch.equal(dx0, dx1)
+    ref = dx0.double().sum(dim=(0, 1, 2))
+    assert float(((db.double() - 0.5) - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-4
+    B, H, W, _ = shape
+    gp = q(rnd((B, H // 2, W // 2, C), 5), dtype).to(dev).to(dtype)
+    p0, p1 = torch.empty(shape, dtype=dtype, device=dev), torch.empty(shape, dtype=dtype, device=dev)
+    ops.maxpool2_act_bwd(y, gp, p0, ops.ACT_LEAKY)
+    db2 = torch.zeros((C,), dtype=torch.float32, device=dev)
+    ops.maxpool2_act_bwd(y, gp, p1, ops.ACT_LEAKY, dbias=db2)
+    assert torch.equal(p0, p1)
+    ref2 = p0.double().sum(dim=(0, 1, 2))
+    assert float((db2.double() - ref2).abs().max()) <= 1e-5 * float(ref2.abs().max()) + 1e-4
