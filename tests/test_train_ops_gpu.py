@@ -366,7 +366,8 @@ def test_act_pool_bwd_with_bias_gradient(shape, dtype):
     ops.act_bwd(y, g1, ops.ACT_LEAKY, dx1, g2=g2, act2=ops.ACT_RELU, dbias=db)
     assert torch.equal(dx0, dx1)
     ref = dx0.double().sum(dim=(0, 1, 2))
-    assert float(((db.double() - 0.5) - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-4
+    # (fp32 partial sums + atomics: error relative to the sum of magnitudes)
+    assert float(((db.double() - 0.5) - ref).abs().max()) <= 2e-6 * float(dx0.double().abs().sum(dim=(0, 1, 2)).max()) + 1e-5
     B, H, W, _ = shape
     gp = q(rnd((B, H // 2, W // 2, C), 5), dtype).to(dev).to(dtype)
     p0, p1 = torch.empty(shape, dtype=dtype, device=dev), torch.empty(shape, dtype=dtype, device=dev)
@@ -375,4 +376,4 @@ def test_act_pool_bwd_with_bias_gradient(shape, dtype):
     ops.maxpool2_act_bwd(y, gp, p1, ops.ACT_LEAKY, dbias=db2)
     assert torch.equal(p0, p1)
     ref2 = p0.double().sum(dim=(0, 1, 2))
-    assert float((db2.double() - ref2).abs().max()) <= 1e-5 * float(ref2.abs().max()) + 1e-4
+    assert float((db2.double() - ref2).abs().max()) <= 2e-6 * float(p0.double().abs().sum(dim=(0, 1, 2)).max()) + 1e-5
