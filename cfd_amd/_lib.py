@@ -42,6 +42,8 @@ SIGNATURES = {
     "cfd_conv_forward_stats": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cfd_conv_pool2_fusable": (_i, [C.POINTER(ConvDesc)]),
     "cfd_conv_forward_pool2": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
+    "cfd_conv_pool2_keep_fusable": (_i, [C.POINTER(ConvDesc)]),
+    "cfd_conv_forward_pool2_keep": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cfd_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cfd_pack_convT_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cfd_pack_dense_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -24,6 +24,10 @@ struct IgemmParams {
   float *stat_sum, *stat_sq;   // optional fused BatchNorm statistics [B][Cout] (accumulated with atomics), or NULL
   int hw_shift, wq_shift;      // log2(Hq*Wq), log2(Wq) when both are powers of two (every reference grid), else -1
   int pool;                    // 1: the epilogue max-pools 2x2 and y is the POOLED tensor [B][Ho/2][Wo/2][Cout] (igemm256 only)
+                               // 2: y is the unpooled activation as usual AND y2 (channel stride ldy2) receives the pooled
+                               //    tensor from the same staged tile (igemm256h only: training keeps both)
+  char *y2;
+  int ldy2;
 };
 
 // first K tile of split-K slice sk (slice = [k_slice(sk), k_slice(sk + 1))): ktiles * sk < 2^31 (host: ktiles <= 16 taps *
@@ -96,5 +100,7 @@ bool igemm256_eligible(const IgemmParams &p, int dtype);
 int igemm256_launch(const IgemmParams &p, int dtype, hipStream_t st);
 int igemm256_block_count(const IgemmParams &p);
 int igemm256_ntile(const IgemmParams &p);
+// igemm256h.hip: does the patch-staged kernel take this launch (p prepared as by igemm256_launch)?
+bool igemm256h_eligible(const IgemmParams &p, int dtype, int ntile);
 
 }  // namespace cfd

@@ -511,6 +511,36 @@ extern "C" int cfd_conv_pool2_fusable(const cfd_conv_desc *d) {
   return d && pool2_fusable(d, p) ? 1 : 0;
 }
 
+// training form: y = the unpooled activation, y_pooled = MaxPooling2D(2,2) of it, one launch (patch-staged bf16 kernel)
+static bool pool2_keep_fusable(const cfd_conv_desc *d, IgemmParams &p) {
+  if (!pool2_fusable(d, p) || d->dtype != CFD_BF16 || tuning(CFD_TUNE_IGEMM256_PD) >= 0) return false;
+  p.pool = 2;
+  p.mtiles = cdiv(p.M, 256);
+  return igemm256h_eligible(p, d->dtype, 256);
+}
+
+extern "C" int cfd_conv_pool2_keep_fusable(const cfd_conv_desc *d) {
+  IgemmParams p;
+  return d && pool2_keep_fusable(d, p) ? 1 : 0;
+}
+
+extern "C" int cfd_conv_forward_pool2_keep(const cfd_conv_desc *d, const void *x, const void *w, const float *bias, void *y,
+                                           void *y_pooled, int ld_pooled, void *stream) {
+  IgemmParams p;
+  CFD_REQUIRE(d != nullptr, "desc is NULL");
+  CFD_REQUIRE(pool2_keep_fusable(d, p),
+              "conv + kept activation + 2x2 max-pool cannot be fused for this shape (ask cfd_conv_pool2_keep_fusable): bf16, "
+              "3x3 stride-1 conv, split_k = 1, Cout %% 256 == 0, Cin %% 64 == 0, height %% 8 == 0, width %% 128 == 0, a "
+              "monotone activation");
+  CFD_REQUIRE(x && w && y && y_pooled, "NULL tensor pointer");
+  CFD_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)y_pooled & 15) == 0 && ld_pooled % 8 == 0 && ld_pooled >= d->Cout,
+              "y and y_pooled must be 16-byte aligned, ld_pooled a multiple of 8 and >= Cout");
+  p.x = (const char *)x; p.w = (const char *)w; p.bias = bias; p.y = (char *)y; p.ws = nullptr;
+  p.y2 = (char *)y_pooled; p.ldy2 = ld_pooled;
+  p.pool = 2;
+  return igemm256_launch(p, d->dtype, (hipStream_t)stream);
+}
+
 extern "C" int cfd_conv_forward_pool2(const cfd_conv_desc *d, const void *x, const void *w, const float *bias, void *y,
                                       void *stream) {
   IgemmParams p;

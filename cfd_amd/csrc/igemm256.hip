@@ -1235,13 +1235,15 @@ int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   // staged bf16 output: whole-tile kernel only (n tile 256), no split-K, 16-B aligned rows
   P.stage_out = ntile == 256 && p.out_bf16 && p.split_k == 1 && p.ldy % 8 == 0 && ((uintptr_t)p.y & 15) == 0 &&
                 p.act != CFD_ACT_SIGMOID && tuning(CFD_TUNE_STAGED_OUT) != 0;
+  const int pdt = tuning(CFD_TUNE_IGEMM256_PD);
   if (p.pool) {
     // (cfd_conv_forward_pool2 checked the shape: stride-1 conv, no split-K, Wq % 128 == 0, Hq even, monotone activation)
     CFD_REQUIRE(ntile == 256 && p.nclass == 1 && p.split_k == 1 && !p.stat_sum && p.M % 256 == 0, "pooled epilogue: bad launch");
+    CFD_REQUIRE(p.pool == 1 || (pdt < 0 && igemm256h_eligible(p, dtype, ntile) && p.y2),
+                "pooled epilogue that keeps the unpooled tensor: patch-staged kernel only");
     P.stage_out = 0;
   }
   const size_t shmem = (size_t)BIAS256_OFF + 1024;   // stages / staged output tile, then the n tile's bias
-  const int pdt = tuning(CFD_TUNE_IGEMM256_PD);
   // stride-1 tap grids on whole 8 x 32 pixel tiles: the activation operand is staged once per channel chunk (igemm256h.hip)
   if (pdt < 0 && igemm256h_eligible(p, dtype, ntile))
     return igemm256h_launch(p, ntile, P.xbytes, P.wbytes, P.cls_fast, P.stage_out, st, cores);

@@ -395,7 +395,17 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
       o.x = mx(a4.x, b4.x, c4.x, d4.x); o.y = mx(a4.y, b4.y, c4.y, d4.y);
       o.z = mx(a4.z, b4.z, c4.z, d4.z); o.w = mx(a4.w, b4.w, c4.w, d4.w);
       const int64_t opix = ((int64_t)b * (p.Hq >> 1) + (ty0 >> 1) + py) * (p.Wq >> 1) + (tx0 >> 1) + px;
-      *(uint4 *)(p.y + (opix * p.ldy + n0) * 2 + ck * 16) = o;
+      if (p.pool == 2) *(uint4 *)(p.y2 + (opix * p.ldy2 + n0) * 2 + ck * 16) = o;
+      else *(uint4 *)(p.y + (opix * p.ldy + n0) * 2 + ck * 16) = o;
+    }
+    if (p.pool == 2) {   // training: the unpooled activation too (the pool's backward needs it), from the same staged tile
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int ml = wave * 32 + it * 2 + half;
+        const int64_t opix = out_pixel(ml);
+        const uint4 v = *(const uint4 *)(stg + ml * OUT_ROW + ck * 16);
+        *(uint4 *)(p.y + (opix * p.ldy + n0) * 2 + ck * 16) = v;
+      }
     }
   } else if (P.stage_out) {
     // ---- staged epilogue: fragments (bias + activation applied, bf16) -> LDS [pixel][channel] -> whole pixel rows

@@ -485,15 +485,22 @@ class CnnRegressor(_Net):
             ops.conv_forward_pool2(g3, P.c("g4.kernel"), P.m("g4.bias"), CONV_K3S1, 256, act=ACT_RELU, out=g5)
         else:
             g4 = self.buf(pl, "g4", (B, H // 2, W // 2, 256))
-            ops.conv_forward(g3, P.c("g4.kernel"), P.m("g4.bias"), CONV_K3S1, 256, act=ACT_RELU, out=g4)
-            ops.maxpool2(g4, out=g5)
+            if training and ops.conv_pool2_keep_fusable(g3, CONV_K3S1, 256, ACT_RELU):
+                # training: the pooled tensor is written next to the unpooled one from the same output tile
+                ops.conv_forward_pool2_keep(g3, P.c("g4.kernel"), P.m("g4.bias"), CONV_K3S1, 256, ACT_RELU, g4, g5)
+            else:
+                ops.conv_forward(g3, P.c("g4.kernel"), P.m("g4.bias"), CONV_K3S1, 256, act=ACT_RELU, out=g4)
+                ops.maxpool2(g4, out=g5)
         g7 = self.buf(pl, "g7", (B, H // 8, W // 8, 512))
         if not training and ops.conv_pool2_fusable(g5, CONV_K3S1, 512, ACT_RELU):
             ops.conv_forward_pool2(g5, P.c("g6.kernel"), P.m("g6.bias"), CONV_K3S1, 512, act=ACT_RELU, out=g7)
         else:
             g6 = self.buf(pl, "g6", (B, H // 4, W // 4, 512))
-            ops.conv_forward(g5, P.c("g6.kernel"), P.m("g6.bias"), CONV_K3S1, 512, act=ACT_RELU, out=g6)
-            ops.maxpool2(g6, out=g7)
+            if training and ops.conv_pool2_keep_fusable(g5, CONV_K3S1, 512, ACT_RELU):
+                ops.conv_forward_pool2_keep(g5, P.c("g6.kernel"), P.m("g6.bias"), CONV_K3S1, 512, ACT_RELU, g6, g7)
+            else:
+                ops.conv_forward(g5, P.c("g6.kernel"), P.m("g6.bias"), CONV_K3S1, 512, act=ACT_RELU, out=g6)
+                ops.maxpool2(g6, out=g7)
         flat = g7.view(B, -1)  # Flatten in (H,W,C) order == NHWC memory order
         f1 = self.buf(pl, "fc1", (B, 256))
         ops.conv_forward(flat, P.c("fc1.kernel"), P.m("fc1.bias"), DENSE, 256, act=ACT_RELU, out=f1)

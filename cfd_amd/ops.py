@@ -226,6 +226,46 @@ def conv_forward_pool2(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Te
     return out
 
 
+def conv_pool2_keep_fusable(x: torch.Tensor, kind: int, cout: int, act: int = ACT_LEAKY, slope: float = LEAKY_SLOPE) -> bool:
+    """can conv + activation (kept) + 2x2 max-pool run as one launch (training forward)?"""
+    B, Hi, Wi, cin = x.shape
+    if x.dtype != torch.bfloat16:
+        return False
+    d = ConvDesc(kind=kind, dtype=_DT[x.dtype], out_dtype=_DT[x.dtype], B=B, Hi=Hi, Wi=Wi, Cin=cin, Cout=cout,
+                 ldx=_nhwc(x)[1], ldy=cout, act=act, leaky_slope=slope, split_k=1)
+    lib = _lib.load()
+    return bool(lib.cfd_conv_pool2_keep_fusable(C.byref(d))) and lib.cfd_conv_suggest_split_k(C.byref(d)) == 1
+
+
+def conv_forward_pool2_keep(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], kind: int, cout: int,
+                            act: int, out: torch.Tensor, pooled: torch.Tensor, slope: float = LEAKY_SLOPE) -> torch.Tensor:
+    """out = act(conv(x, w) + bias) (B, Hi, Wi, cout) AND pooled = MaxPooling2D(2x2)(out), one launch (training forward:
+    the pool's backward needs `out`).  Shapes: see conv_pool2_keep_fusable.  Returns `pooled`."""
+    lib = _lib.load()
+    B, Hi, Wi, cin = x.shape
+    xp, ldx = _nhwc(x)
+    _need(tuple(out.shape) == (B, Hi, Wi, cout) and out.dtype == x.dtype and
+          tuple(pooled.shape) == (B, Hi // 2, Wi // 2, cout) and pooled.dtype == x.dtype,
+          f"conv_forward_pool2_keep: out {tuple(out.shape)} / pooled {tuple(pooled.shape)} do not match {(B, Hi, Wi, cout)}")
+    yp, ldy = _nhwc(out)
+    pp, ldp = _nhwc(pooled)
+    _numel(w, cout * _TAPS[kind] * cin, "conv weight")
+    _numel(bias, cout, "conv bias", torch.float32)
+    if w.dtype != x.dtype:
+        raise _lib.CfdError(f"weight dtype {w.dtype} != activation dtype {x.dtype}")
+    d = ConvDesc(kind=kind, dtype=_DT[x.dtype], out_dtype=_DT[out.dtype], B=B, Hi=Hi, Wi=Wi, Cin=cin, Cout=cout,
+                 ldx=ldx, ldy=ldy, act=act, leaky_slope=slope, split_k=1)
+    if _timer is not None:
+        e0, e1 = _timer.pair()
+        e0.record()
+    check(lib.cfd_conv_forward_pool2_keep(C.byref(d), xp, _ptr(w), _ptr(bias), yp, pp, ldp, _stream()),
+          "cfd_conv_forward_pool2_keep")
+    if _timer is not None:
+        e1.record()
+        _timer.records.append((kind, 2.0 * B * Hi * Wi * cout * _TAPS[kind] * cin, e0, e1))
+    return pooled
+
+
 def pack_conv_weight(keras_hwio: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     kh, kw, cin, cout = keras_hwio.shape
     src = _dev(keras_hwio).contiguous().float()

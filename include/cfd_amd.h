@@ -112,6 +112,15 @@ int cfd_conv_pool2_fusable(const cfd_conv_desc *desc);
 int cfd_conv_forward_pool2(const cfd_conv_desc *desc, const void *x, const void *w, const float *bias, void *y,
                            void *stream);
 
+/* The training form of the same fusion: y is the unpooled activation [B][Hi][Wi][Cout] (channel stride desc->ldy; the
+ * pool's backward needs it) AND y_pooled [B][Hi/2][Wi/2][Cout] (channel stride ld_pooled) its MaxPooling2D((2,2)), both
+ * written from the one staged output tile -- the separate cfd_maxpool2 launch re-read the whole activation
+ * (DeltaP/models/generator.py:31-35 inside DeltaP/train.py:131's train_on_batch).  bf16 only; shapes with
+ * cfd_conv_pool2_keep_fusable() != 0 (those of cfd_conv_pool2_fusable that the patch-staged kernel takes). */
+int cfd_conv_pool2_keep_fusable(const cfd_conv_desc *desc);
+int cfd_conv_forward_pool2_keep(const cfd_conv_desc *desc, const void *x, const void *w, const float *bias, void *y,
+                                void *y_pooled, int ld_pooled, void *stream);
+
 /* weight re-layout: Keras Conv2D (kh,kw,Cin,Cout) fp32 -> packed [Cout][kh][kw][Cin] of `dtype` */
 int cfd_pack_conv_weight(const float *keras_hwio, void *packed, int kh, int kw, int cin, int cout, int dtype,
                          void *stream);

@@ -133,6 +133,32 @@ def test_conv_forward_pool2(kind, B, H, W, cin, cout, act, dtype):
                                bias.to(dev), code, cout, act=code_act)
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,act", [
+    (2, 16, 128, 128, 512, "relu"),       # two chunks, two n tiles
+    (3, 8, 256, 64, 256, "leaky"),        # one chunk, eight tiles per row
+    (1, 24, 128, 192, 256, "relu"),       # three tile rows: a grid that is no power of two
+])
+def test_conv_forward_pool2_keep(B, H, W, cin, cout, act):
+    """the training form of the pooled epilogue (igemm256h, bf16): the unpooled activation AND its 2x2 max-pool from one
+    launch == conv_forward followed by maxpool2, bit for bit (same kernel, same staged tile), into channel slices"""
+    from cfd_amd import ops
+    dtype, dev = torch.bfloat16, "cuda"
+    x = q(rnd((B, H, W, cin), 1), dtype).to(dev).to(dtype)
+    bias = rnd((cout,), 3, 0.1).to(dev)
+    wp = ops.pack_conv_weight(q(rnd((3, 3, cin, cout), 2, 0.05), dtype).to(dev), dtype)
+    code_act = {"leaky": ops.ACT_LEAKY, "relu": ops.ACT_RELU}[act]
+    assert ops.conv_pool2_keep_fusable(x, ops.CONV_K3S1, cout, code_act)
+    full = torch.full((B, H, W, cout + 64), 7.0, dtype=dtype, device=dev)
+    pooled = torch.full((B, H // 2, W // 2, cout + 8), 5.0, dtype=dtype, device=dev)
+    ops.conv_forward_pool2_keep(x, wp, bias, ops.CONV_K3S1, cout, code_act, full[..., 64:], pooled[..., :cout])
+    y = ops.conv_forward(x, wp, bias, ops.CONV_K3S1, cout, act=code_act, split_k=1)
+    two = ops.maxpool2(y)
+    torch.cuda.synchronize()
+    assert torch.equal(full[..., 64:], y) and torch.equal(pooled[..., :cout], two)
+    assert bool((full[..., :64] == 7.0).all()) and bool((pooled[..., cout:] == 5.0).all())
+    assert not ops.conv_pool2_keep_fusable(x.float(), ops.CONV_K3S1, cout, code_act)      # bf16 only
+
+
 @pytest.mark.parametrize("pd", [36, 37])
 @pytest.mark.parametrize("kind,B,H,W,cin,cout,split_k", [
     ("k4s2", 4, 32, 128, 64, 512, 1),     # 32 tiles of 16 K tiles: 4 per workgroup on 8 workgroups, 1 on 32
