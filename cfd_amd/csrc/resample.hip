@@ -376,6 +376,182 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const double *__restri
   sidx[beg + pos] = (int)(g - beg);
 }
 
+// ---- everything that precedes the search, for ONE case per block (round 3) -----------------------------------------
+// resample_init + points_pass + case_setup + bin_count / bin_scan / bin_scatter + the memset of the cell counts were six
+// launches and a memset whose ~100 us were a third of a 256-case call although each case's share is a few microseconds of
+// work: all of it is per-case, so one block of 1024 threads walks the phases with block barriers in between -- slice
+// accumulators and bounding box in LDS (no global accumulators at all), then the wall, the cell grid, and the counting sort
+// with this case's counters in global memory (zeroed here, by the block that uses them).  Same arithmetic, same results;
+// used when the average case fits a block's sweep (the multi-launch path stays for huge cases, K blocks per case).
+constexpr int PREP_T = 1024;
+
+__global__ __launch_bounds__(PREP_T) void case_prepare_kernel(
+    const double *__restrict__ pts, const int64_t *__restrict__ offs, const double *__restrict__ zs, int S, double tol1,
+    double tol2, const double *__restrict__ zf, int W, double *__restrict__ wall, int64_t wall_stride,
+    double *__restrict__ grid, int *__restrict__ start, int *__restrict__ cnt, int *__restrict__ cell,
+    double2 *__restrict__ syz, double2 *__restrict__ spu, int *__restrict__ sidx, double pts_per_cell) {
+  extern __shared__ unsigned long long lacc[];      // [4][S] mn1 mx1 mn2 mx2 | double [4][S] zs, xp, lo, hi | int [2][S] NaN counts
+  double *lzs = (double *)(lacc + 4 * S), *xp = lzs + S, *lo = xp + S, *hi = lo + S;
+  int *lnan = (int *)(hi + S);
+  __shared__ unsigned long long lbox[4];
+  __shared__ int part[PREP_T];
+  __shared__ int nvalid;
+  __shared__ double gsh[8];
+  const int cs = blockIdx.x, tid = threadIdx.x;
+  const int64_t beg = offs[cs], end = offs[cs + 1], N = end - beg;
+  const int64_t cap = N > 64 ? N : 64;
+  int *c = cnt + cell_base(cs, beg);
+  int *st = start + cell_base(cs, beg) + cs;
+  for (int s = tid; s < 4 * S; s += PREP_T) lacc[s] = enc(((s / S) & 1) ? -dinf() : dinf());
+  for (int s = tid; s < 2 * S; s += PREP_T) lnan[s] = 0;
+  for (int s = tid; s < S; s += PREP_T) lzs[s] = zs[s];
+  if (tid < 4) lbox[tid] = enc((tid & 1) ? -dinf() : dinf());
+  for (int64_t i = tid; i < cap; i += PREP_T) c[i] = 0;
+  __syncthreads();
+  // ---- points pass (points_pass_kernel's loop with one block per case)
+  {
+    const bool both = !(tol1 <= tol2);
+    double ymn = dinf(), ymx = -dinf(), zmn = dinf(), zmx = -dinf();
+    for (int64_t g = beg + tid; g < end; g += PREP_T) {
+      const double y = pts[g * 5 + 1], z = pts[g * 5 + 2];
+      if ((y - y == 0.0) && (z - z == 0.0)) {
+        ymn = fmin(ymn, y); ymx = fmax(ymx, y); zmn = fmin(zmn, z); zmx = fmax(zmx, z);
+      }
+      if (!(z - z == 0.0)) continue;
+      const double wlo = z - 2.0 * tol2 - 2.0 * tol1, whi = z + 2.0 * tol2 + 2.0 * tol1;
+      int a = 0, b = S;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (lzs[mid] < wlo) a = mid + 1; else b = mid;
+      }
+      const bool ynan = y != y;
+      for (int s = a; s < S && lzs[s] <= whi; ++s) {
+        const double d = fabs(z - lzs[s]);
+        const bool in1 = d < tol1, in2 = d < tol2;
+        if (in1) {
+          if (ynan) atomicAdd(lnan + s, 1);
+          else { atomicMin(lacc + 0 * S + s, enc(y)); atomicMax(lacc + 1 * S + s, enc(y)); }
+        }
+        if (in2 && (both || !in1)) {
+          if (ynan) atomicAdd(lnan + S + s, 1);
+          else { atomicMin(lacc + 2 * S + s, enc(y)); atomicMax(lacc + 3 * S + s, enc(y)); }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ymn = fmin(ymn, __shfl_xor(ymn, o)); ymx = fmax(ymx, __shfl_xor(ymx, o));
+      zmn = fmin(zmn, __shfl_xor(zmn, o)); zmx = fmax(zmx, __shfl_xor(zmx, o));
+    }
+    if ((tid & 63) == 0) {
+      atomicMin(lbox + 0, enc(ymn)); atomicMax(lbox + 1, enc(ymx));
+      atomicMin(lbox + 2, enc(zmn)); atomicMax(lbox + 3, enc(zmx));
+    }
+  }
+  __syncthreads();
+  // ---- slices -> wall block (case_setup_kernel's decode, reading the LDS accumulators)
+  double *w = wall + (int64_t)cs * wall_stride;
+  for (int s = tid; s < S; s += PREP_T) {
+    const bool has1 = lacc[0 * S + s] <= lacc[1 * S + s] || lnan[s] > 0;          // some point within tol1 (:192-195)
+    const bool has2 = lacc[2 * S + s] <= lacc[3 * S + s] || lnan[S + s] > 0;      // else within tol2 (:197-199)
+    double l, h;
+    if (has1) {
+      if (lnan[s] > 0) { l = dnan(); h = dnan(); }                                // np.min / np.max propagate a NaN
+      else { l = dec(lacc[0 * S + s]); h = dec(lacc[1 * S + s]); }
+    } else if (has2) {
+      if (lnan[S + s] > 0) { l = dnan(); h = dnan(); }
+      else { l = dec(lacc[2 * S + s]); h = dec(lacc[3 * S + s]); }
+    } else { l = dnan(); h = dnan(); }
+    w[s] = l;
+    w[S + s] = h;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int s = 0; s < S; ++s) {
+      const double l = w[s], h = w[S + s];
+      if (l == l && h == h) { xp[n] = lzs[s]; lo[n] = l; hi[n] = h; ++n; }
+    }
+    nvalid = n;
+    *(int *)(w + 2 * S + 2 * W) = n;
+    // ---- cell grid: the same choice as case_setup_kernel
+    const double ymn = dec(lbox[0]), ymx = dec(lbox[1]), zmn = dec(lbox[2]), zmx = dec(lbox[3]);
+    const bool any = ymn <= ymx && zmn <= zmx;
+    const double ry = any ? ymx - ymn : 0.0, rz = any ? zmx - zmn : 0.0;
+    const double tcells = floor((double)N / pts_per_cell);
+    const double target = tcells > 1.0 ? tcells : 1.0;
+    int64_t ny = 1, nz = 1;
+    if (ry > 0.0 && rz > 0.0) {
+      const double h = sqrt(ry * rz / target);
+      const double fy = floor(ry / h) + 1.0, fz = floor(rz / h) + 1.0;
+      ny = fy < (double)cap ? (int64_t)fy : cap;
+      nz = fz < (double)cap ? (int64_t)fz : cap;
+    } else if (ry > 0.0) {
+      ny = (int64_t)target < cap ? (int64_t)target : cap;
+    } else if (rz > 0.0) {
+      nz = (int64_t)target < cap ? (int64_t)target : cap;
+    }
+    while (ny * nz > cap) { if (ny >= nz) ny = (ny + 1) / 2; else nz = (nz + 1) / 2; }
+    const double g_y0 = any ? ymn : 0.0, g_z0 = any ? zmn : 0.0;
+    const double g_hy = ry > 0.0 ? ry / (double)ny : 1.0, g_hz = rz > 0.0 ? rz / (double)nz : 1.0;
+    gsh[0] = (double)ny; gsh[1] = (double)nz; gsh[2] = g_y0; gsh[3] = g_z0; gsh[4] = 1.0 / g_hy; gsh[5] = 1.0 / g_hz;
+    gsh[6] = g_hy; gsh[7] = g_hz;
+  }
+  __syncthreads();
+  if (tid < 8) grid[(int64_t)cs * 8 + tid] = gsh[tid];
+  {
+    const int n = nvalid;
+    for (int j = tid; j < W; j += PREP_T) {
+      double l = dnan(), h = dnan();
+      if (n > 0) { l = np_interp(zf[j], xp, lo, n); h = np_interp(zf[j], xp, hi, n); }
+      w[2 * S + j] = l;
+      w[2 * S + W + j] = h;
+    }
+  }
+  // ---- counting sort of the points by cell
+  CaseGrid G;
+  G.ny = (int)gsh[0]; G.nz = (int)gsh[1]; G.y0 = gsh[2]; G.z0 = gsh[3]; G.invy = gsh[4]; G.invz = gsh[5]; G.hy = gsh[6]; G.hz = gsh[7];
+  for (int64_t g = beg + tid; g < end; g += PREP_T) {
+    const int cy = bin1(pts[g * 5 + 1], G.y0, G.invy, G.hy, G.ny);
+    const int cz = bin1(pts[g * 5 + 2], G.z0, G.invz, G.hz, G.nz);
+    const int cc = cy * G.nz + cz;
+    cell[g] = cc;
+    atomicAdd(c + cc, 1);
+  }
+  __syncthreads();
+  const int ncell = G.ny * G.nz;
+  {
+    const int per = (ncell + PREP_T - 1) / PREP_T;
+    const int a = tid * per < ncell ? tid * per : ncell, b = (a + per < ncell) ? a + per : ncell;
+    int sum = 0;
+    for (int i = a; i < b; ++i) sum += c[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < PREP_T; o <<= 1) {
+      const int v = (tid >= o) ? part[tid - o] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int i = a; i < b; ++i) {
+      const int v = c[i];
+      st[i] = run;
+      run += v;
+      c[i] = 0;
+    }
+    if (tid == PREP_T - 1) st[ncell] = part[PREP_T - 1];
+  }
+  __syncthreads();
+  for (int64_t g = beg + tid; g < end; g += PREP_T) {
+    const int cc = cell[g];
+    const int pos = st[cc] + atomicAdd(c + cc, 1);
+    syz[beg + pos] = make_double2(pts[g * 5 + 1], pts[g * 5 + 2]);
+    spu[beg + pos] = make_double2(pts[g * 5 + 3], pts[g * 5 + 4]);
+    sidx[beg + pos] = (int)(g - beg);
+  }
+}
+
 // ordering point for LDS traffic between the lanes of ONE wave (its LDS operations execute in program order; this keeps
 // the compiler from moving them across and waits for the writes)
 __device__ __forceinline__ void wave_sync() {
@@ -648,11 +824,22 @@ int resample_launch(const double *pts, const int64_t *case_offsets, int ncase, i
   double2 *syz = (double2 *)(base + L.o_syz);
   double2 *spu = (double2 *)(base + L.o_spu);
   int *sidx = (int *)(base + L.o_sidx);
+  const double ppc = tuning(CFD_TUNE_RESAMPLE_DENSITY) > 0 ? tuning(CFD_TUNE_RESAMPLE_DENSITY) / 4.0 : 1.5;
+  const int pblocks = cdiv(total, 256);
+  // one block per case does everything before the search when the average case is a block's sweep (<= 32 Ki points) and the
+  // slice tables fit its LDS; cfd_set_tuning(CFD_TUNE_RESAMPLE_FUSED, 0) keeps the multi-launch path (tests run both)
+  const size_t prep_lds = (size_t)8 * S * 8 + (size_t)2 * S * 4;
+  const bool fused = tuning(CFD_TUNE_RESAMPLE_FUSED) != 0 && S <= 1024 && total / ncase <= 32768;
+  if (fused) {
+    if (int e_ = set_max_lds((const void *)case_prepare_kernel, (int)prep_lds)) return e_;
+    hipLaunchKernelGGL(case_prepare_kernel, dim3(ncase), dim3(PREP_T), prep_lds, st, pts, case_offsets, z_samples, S, tol1,
+                       tol2, z_final, W, wall, L.wall_stride, grid, start, cnt, cell, syz, spu, sidx, ppc);
+    CFD_LAUNCH_CHECK();
+  } else {
   const int64_t ninit = (int64_t)ncase * 4 * S;
   hipLaunchKernelGGL(resample_init_kernel, dim3(cdiv(ninit, 256)), dim3(256), 0, st, sacc, scnt, bbox, ncase, S);
   CFD_LAUNCH_CHECK();
   CFD_HIP(hipMemsetAsync(cnt, 0, (size_t)(L.o_cell - L.o_cnt), st));
-  const int pblocks = cdiv(total, 256);
   if (pblocks > 0) {
     // blocks per case from the AVERAGE case size (the per-case sizes live on the device): ~8 points per thread
     int64_t K = (total / ncase + 2047) / 2048;
@@ -664,7 +851,7 @@ int resample_launch(const double *pts, const int64_t *case_offsets, int ncase, i
   }
   hipLaunchKernelGGL(case_setup_kernel, dim3(ncase), dim3(256), 3 * S * sizeof(double), st, case_offsets, z_samples, S,
                      z_final, W, (const unsigned long long *)sacc, (const int *)scnt, (const unsigned long long *)bbox,
-                     wall, L.wall_stride, grid, tuning(CFD_TUNE_RESAMPLE_DENSITY) > 0 ? tuning(CFD_TUNE_RESAMPLE_DENSITY) / 4.0 : 1.5);
+                     wall, L.wall_stride, grid, ppc);
   CFD_LAUNCH_CHECK();
   if (pblocks > 0) {
     hipLaunchKernelGGL(bin_count_kernel, dim3(pblocks), dim3(256), 0, st, pts, case_offsets, ncase, total,
@@ -677,6 +864,7 @@ int resample_launch(const double *pts, const int64_t *case_offsets, int ncase, i
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(pblocks), dim3(256), 0, st, pts, case_offsets, ncase, total,
                        (const int *)cell, (const int *)start, cnt, syz, spu, sidx);
     CFD_LAUNCH_CHECK();
+  }
   }
   const int64_t tiles = (int64_t)cdiv(W, TILE_W) * cdiv(H, TILE_H);
   CFD_REQUIRE(tiles * ncase < (1LL << 31), "too many tiles in one call");

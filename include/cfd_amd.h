@@ -53,9 +53,12 @@ const char *cfd_last_error(void);
  *                         | 2: as 1, and every layer on 128-wide n tiles runs the CO-RESIDENT form (32-channel K tiles, 69 KiB
  *                         of LDS, two workgroups per CU) | 3: every patch-eligible layer does | -1 (default): as 1, plus the
  *                         co-resident form for 128-wide layers of at most 16 K tiles (per-tile overhead dominates there)
+ *   CFD_TUNE_RESAMPLE_FUSED  -1 / 1: everything before the resample's search runs as ONE launch, a block per case (cases of up to
+ *                         32 Ki points on average) | 0: the separate init / points / set-up / counting-sort launches
  */
 typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_WGRAD256 = 2, CFD_TUNE_CLASS_ORDER = 3,
-               CFD_TUNE_STAGED_OUT = 4, CFD_TUNE_RESAMPLE_DENSITY = 5, CFD_TUNE_NTILE = 6, CFD_TUNE_PATCH = 7, CFD_TUNE_COUNT = 8 } cfd_tuning_key;
+               CFD_TUNE_STAGED_OUT = 4, CFD_TUNE_RESAMPLE_DENSITY = 5, CFD_TUNE_NTILE = 6, CFD_TUNE_PATCH = 7,
+               CFD_TUNE_RESAMPLE_FUSED = 8, CFD_TUNE_COUNT = 9 } cfd_tuning_key;
 int cfd_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------

@@ -152,10 +152,15 @@ def test_conv_forward_pool2_keep(B, H, W, cin, cout, act):
     full = torch.full((B, H, W, cout + 64), 7.0, dtype=dtype, device=dev)
     pooled = torch.full((B, H // 2, W // 2, cout + 8), 5.0, dtype=dtype, device=dev)
     ops.conv_forward_pool2_keep(x, wp, bias, ops.CONV_K3S1, cout, code_act, full[..., 64:], pooled[..., :cout])
-    y = ops.conv_forward(x, wp, bias, ops.CONV_K3S1, cout, act=code_act, split_k=1)
+    ops.set_tuning(ops.TUNE_IGEMM256, 1)      # the same kernel for the two-launch reference (small K: the heuristic takes the 128 x 128 one)
+    try:
+        y = ops.conv_forward(x, wp, bias, ops.CONV_K3S1, cout, act=code_act, split_k=1)
+    finally:
+        ops.set_tuning(ops.TUNE_IGEMM256, -1)
     two = ops.maxpool2(y)
     torch.cuda.synchronize()
-    assert torch.equal(full[..., 64:], y) and torch.equal(pooled[..., :cout], two)
+    assert torch.equal(full[..., 64:], y)
+    assert torch.equal(pooled[..., :cout], two)
     assert bool((full[..., :64] == 7.0).all()) and bool((pooled[..., cout:] == 5.0).all())
     assert not ops.conv_pool2_keep_fusable(x.float(), ops.CONV_K3S1, cout, code_act)      # bf16 only
 
@@ -649,6 +654,44 @@ def test_resample_openfoam_scale_points():
     out = ops.resample_nearest([big, small], 32, 128)
     assert np.array_equal(out[0].view(np.uint64), OR.resample(big, 32, 128, chunk=128).view(np.uint64))
     assert np.array_equal(out[1].view(np.uint64), OR.resample(small, 32, 128).view(np.uint64))
+
+
+def test_resample_fused_prepare_equals_separate_launches():
+    """round 3: everything before the search (accumulators, slice walls, cell grid, counting sort) runs as ONE launch with
+    a block per case; cfd_set_tuning(CFD_TUNE_RESAMPLE_FUSED, 0) keeps the separate launches.  Both must give the same
+    table bit for bit (and the oracle's): ragged cases, a 100 000-point case swept by a single block, NaN slices, a
+    one-point case."""
+    from cfd_amd import ops, synthetic
+    rng = np.random.default_rng(23)
+    sets = [
+        ([synthetic.scattered_case(s, n_z=101, n_y=9 + 4 * s, jitter=0.2) for s in range(5)], 32, 128),
+        ([_wall_points(rng, 100_000)] + [_wall_points(rng, 500 + 300 * k) for k in range(3)], 16, 64),
+        ([_wall_points(rng, 1), _wall_points(rng, 2000)], 13, 37),
+    ]
+    sparse = synthetic.scattered_case(3, n_z=101, n_y=11, jitter=0.1)
+    sparse[::7, 1] = np.nan                                            # NaN y: those slices drop out (np.min propagates)
+    sets.append(([sparse, synthetic.scattered_case(4, jitter=0.3)], 16, 64))
+    for cases, H, W in sets:
+        try:
+            ops.set_tuning(ops.TUNE_RESAMPLE_FUSED, 0)
+            try:
+                a = ops.resample_nearest(cases, H, W)
+            except ValueError as e:
+                a = e
+            ops.set_tuning(ops.TUNE_RESAMPLE_FUSED, -1)
+            try:
+                b = ops.resample_nearest(cases, H, W)
+            except ValueError as e:
+                b = e
+        finally:
+            ops.set_tuning(ops.TUNE_RESAMPLE_FUSED, -1)
+        if isinstance(a, ValueError) or isinstance(b, ValueError):
+            assert isinstance(a, ValueError) and isinstance(b, ValueError) and str(a) == str(b)
+            continue
+        for x, y, c in zip(a, b, cases):
+            assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
+            if len(c) <= 5000:
+                assert np.array_equal(y.view(np.uint64), OR.resample(c, H, W).view(np.uint64))
 
 
 def test_resample_no_slices_raises():
