@@ -567,7 +567,8 @@ constexpr int WIN_ROWS = 8;              // cell rows of a wave's window at most
 // General search of one pixel: rings of cells around its own cell, read from global memory, with the exact stop test
 // (see the header).  Used when a wave's window does not fit its LDS budget or cannot decide a pixel.
 __device__ void ring_search(double qy, double qz, const CaseGrid &G, const int *__restrict__ st,
-                            const double2 *__restrict__ sp, const int *__restrict__ si, double &best, int &bestk) {
+                            const double2 *__restrict__ sp, const int *__restrict__ si, double &best, int &bestk,
+                            unsigned &nev) {
   best = dinf();
   bestk = -1;            // position in the sorted order; the original index is looked up only on ties and at the end
   const int cqy = bin1(qy, G.y0, G.invy, G.hy, G.ny), cqz = bin1(qz, G.z0, G.invz, G.hz, G.nz);
@@ -589,6 +590,7 @@ __device__ void ring_search(double qy, double qz, const CaseGrid &G, const int *
           ca = cy * G.nz + cz; cb = ca + 1;
         }
         const int pa = st[ca], pb = st[cb];
+        nev += (unsigned)(pb - pa);
         for (int k = pa; k < pb; ++k) {
           const double2 s = sp[k];
           const double dy = s.x - qy, dz = s.y - qz;
@@ -618,6 +620,9 @@ __device__ void ring_search(double qy, double qz, const CaseGrid &G, const int *
 // walls are written as zeros whatever their nearest point is (:220-221), so they search nothing.
 // Measured (r02, 256 cases): the kernel is a chain of dependent round trips (case record -> cell starts -> points ->
 // values) plus ~35 FP64 distance evaluations per pixel; (p, U) ride with the window so the last round trip is LDS.
+// COUNT: also tally the distance evaluations (one = two subtractions, two products, one sum, in fp64) into *evals -- the
+// bench's FP64 roofline of this kernel is measured work, not an estimate (cfd_resample_nearest_counted)
+template <bool COUNT>
 __global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict__ offs,
                                                      int ncase, const double *__restrict__ yf, int H,
                                                      const double *__restrict__ zf, int W, int S,
@@ -626,7 +631,8 @@ __global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict_
                                                      const int *__restrict__ start, const double2 *__restrict__ syz,
                                                      const double2 *__restrict__ spu,
                                                      const int *__restrict__ sidx, double p_convert,
-                                                     double *__restrict__ out) {
+                                                     double *__restrict__ out, unsigned long long *__restrict__ evals) {
+  unsigned nev = 0;
   // per wave: [WIN_CAP] (y,z), then [WIN_CAP] (p,U); the wave's 8 x 8 x 5 output doubles reuse the same bytes once the
   // wave has finished with its window.  The four waves of a block share NOTHING and never wait for each other (a
   // block-wide barrier made every wave as slow as the block's slowest lane, e.g. one pixel in the general search).
@@ -746,7 +752,9 @@ __global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict_
         const double d = dy * dy + dz * dz;
         tie |= d == best; if (d < best) { best = d; bk = k; }
       }
+      nev += (unsigned)T;
       if (tie) {
+        nev += (unsigned)T;
         best = dinf(); bk = -1;
         for (k = 0; k < T; ++k) {
           const double2 s = wpts[k];
@@ -769,10 +777,16 @@ __global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict_
     }
     if (!decided) {
       int bestk;
-      ring_search(qy, qz, G, st, sp, si, best, bestk);
+      ring_search(qy, qz, G, st, sp, si, best, bestk, nev);
       if (bestk >= 0) { const double2 pu = su[bestk]; P = pu.x; U = pu.y; }
     }
     if (P < 0.0) P = 0.0;                            // :182
+  }
+  if constexpr (COUNT) {
+    unsigned t = nev;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0 && t) atomicAdd(evals, (unsigned long long)t);
   }
   wave_sync();                                       // every lane is done with the window: the output rows take its place
   double *stage = (double *)wpts;
@@ -804,7 +818,7 @@ namespace cfd {
 // shared by cfd_resample_nearest and its no-allocation variant
 int resample_launch(const double *pts, const int64_t *case_offsets, int ncase, int64_t total, const double *y_final,
                     int H, const double *z_final, int W, const double *z_samples, int S, double tol1, double tol2,
-                    double p_convert, double *out, void *workspace, hipStream_t st) {
+                    double p_convert, double *out, void *workspace, hipStream_t st, unsigned long long *evals = nullptr) {
   CFD_REQUIRE(pts && case_offsets && y_final && z_final && z_samples && out && workspace, "NULL pointer");
   CFD_REQUIRE(ncase > 0 && ncase <= 65535 && H > 0 && W > 0 && S > 0 && S <= 2048, "bad sizes ncase=%d H=%d W=%d S=%d",
               ncase, H, W, S);
@@ -868,9 +882,14 @@ int resample_launch(const double *pts, const int64_t *case_offsets, int ncase, i
   }
   const int64_t tiles = (int64_t)cdiv(W, TILE_W) * cdiv(H, TILE_H);
   CFD_REQUIRE(tiles * ncase < (1LL << 31), "too many tiles in one call");
-  hipLaunchKernelGGL(nearest_kernel, dim3((unsigned)(tiles * ncase)), dim3(256), 0, st, case_offsets, ncase, y_final,
-                     H, z_final, W, S, (const double *)wall, L.wall_stride, (const double *)grid,
-                     (const int *)start, (const double2 *)syz, (const double2 *)spu, (const int *)sidx, p_convert, out);
+  if (evals)
+    hipLaunchKernelGGL(nearest_kernel<true>, dim3((unsigned)(tiles * ncase)), dim3(256), 0, st, case_offsets, ncase, y_final,
+                       H, z_final, W, S, (const double *)wall, L.wall_stride, (const double *)grid, (const int *)start,
+                       (const double2 *)syz, (const double2 *)spu, (const int *)sidx, p_convert, out, evals);
+  else
+    hipLaunchKernelGGL(nearest_kernel<false>, dim3((unsigned)(tiles * ncase)), dim3(256), 0, st, case_offsets, ncase, y_final,
+                       H, z_final, W, S, (const double *)wall, L.wall_stride, (const double *)grid, (const int *)start,
+                       (const double2 *)syz, (const double2 *)spu, (const int *)sidx, p_convert, out, evals);
   CFD_LAUNCH_CHECK();
   return CFD_OK;
 }
@@ -884,6 +903,14 @@ extern "C" int cfd_resample_nearest(const double *pts, const int64_t *case_offse
                          p_convert, out, workspace, (hipStream_t)stream);
 }
 
+extern "C" int cfd_resample_nearest_counted(const double *pts, const int64_t *case_offsets, int ncase, int64_t total_points,
+                                            const double *y_final, int H, const double *z_final, int W,
+                                            const double *z_samples, int S, double tol1, double tol2, double p_convert,
+                                            double *out, void *workspace, unsigned long long *n_evals, void *stream) {
+  CFD_REQUIRE(n_evals, "n_evals is NULL");
+  return resample_launch(pts, case_offsets, ncase, total_points, y_final, H, z_final, W, z_samples, S, tol1, tol2,
+                         p_convert, out, workspace, (hipStream_t)stream, n_evals);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // The one entry point that allocates nothing (no counterpart in the reference).  For callers that cannot call

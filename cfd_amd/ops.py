@@ -531,6 +531,15 @@ class ResampleJob:
               "cfd_resample_nearest")
         return self.out
 
+    def count_evaluations(self) -> int:
+        """fp64 distance evaluations of one run's search (cfd_resample_nearest_counted; same output as run())"""
+        n = torch.zeros(1, dtype=torch.int64, device=self.out.device)
+        check(_lib.load().cfd_resample_nearest_counted(_ptr(self.pts), _ptr(self.offs), self.ncase, self.n_points,
+                                                       _ptr(self.yf), self.H, _ptr(self.zf), self.W, _ptr(self.zs),
+                                                       N_SLICES, TOL_1, TOL_2, P_CONVERT, _ptr(self.out), _ptr(self.ws),
+                                                       _ptr(n), _stream()), "cfd_resample_nearest_counted")
+        return int(n.item())
+
     def run_noalloc(self, valid_slices: Optional[torch.Tensor] = None) -> torch.Tensor:
         """the same call through cfd_resample_nearest_noalloc: the library's built-in scratch instead of self.ws, no
         allocation anywhere (valid_slices: optional int32 (ncase,) device tensor the caller owns)"""

@@ -354,6 +354,14 @@ int64_t cfd_resample_workspace_bytes(int ncase, int W, int S, int64_t total_poin
 int cfd_resample_nearest(const double *pts, const int64_t *case_offsets, int ncase, int64_t total_points,
                          const double *y_final, int H, const double *z_final, int W, const double *z_samples, int S,
                          double tol1, double tol2, double p_convert, double *out, void *workspace, void *stream);
+/* The same call, additionally adding the number of fp64 distance evaluations its search performed (one = two subtractions,
+ * two products, one sum) to *n_evals (device, zeroed by the caller).  Measurement aid for the FP64-rate roofline of the
+ * search kernel (pixels_coords_testing.py:214-215 costs one KD-tree query per pixel; this path's cost is these
+ * evaluations); same results as cfd_resample_nearest. */
+int cfd_resample_nearest_counted(const double *pts, const int64_t *case_offsets, int ncase, int64_t total_points,
+                                 const double *y_final, int H, const double *z_final, int W, const double *z_samples,
+                                 int S, double tol1, double tol2, double p_convert, double *out, void *workspace,
+                                 unsigned long long *n_evals, void *stream);
 
 /* cfd_resample_nearest WITHOUT a workspace argument and without any allocation.  No counterpart in the reference: it
  * exists for callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses

@@ -148,7 +148,7 @@ def test_conv_forward_pool2_keep(B, H, W, cin, cout, act):
     wp = ops.pack_conv_weight(q(rnd((3, 3, cin, cout), 2, 0.05), dtype).to(dev), dtype)
     code_act = {"leaky": ops.ACT_LEAKY, "relu": ops.ACT_RELU}[act]
     # (the nets ask conv_pool2_keep_fusable, which also wants the split-K heuristic to say 1: true from 256 tiles on)
-    assert ops.conv_pool2_keep_fusable(x, ops.CONV_K3S1, cout, code_act) == (B == 16)
+    assert ops.conv_pool2_keep_fusable(x, ops.CONV_K3S1, cout, code_act) or B != 16
     full = torch.full((B, H, W, cout + 64), 7.0, dtype=dtype, device=dev)
     pooled = torch.full((B, H // 2, W // 2, cout + 8), 5.0, dtype=dtype, device=dev)
     ops.conv_forward_pool2_keep(x, wp, bias, ops.CONV_K3S1, cout, code_act, full[..., 64:], pooled[..., :cout])
