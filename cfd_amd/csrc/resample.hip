@@ -390,9 +390,9 @@ __global__ __launch_bounds__(PREP_T) void case_prepare_kernel(
     double tol2, const double *__restrict__ zf, int W, double *__restrict__ wall, int64_t wall_stride,
     double *__restrict__ grid, int *__restrict__ start, int *__restrict__ cnt, int *__restrict__ cell,
     double2 *__restrict__ syz, double2 *__restrict__ spu, int *__restrict__ sidx, double pts_per_cell) {
-  extern __shared__ unsigned long long lacc[];      // [4][S] mn1 mx1 mn2 mx2 | double [4][S] zs, xp, lo, hi | int [2][S] NaN counts
-  double *lzs = (double *)(lacc + 4 * S), *xp = lzs + S, *lo = xp + S, *hi = lo + S;
-  int *lnan = (int *)(hi + S);
+  extern __shared__ unsigned long long lacc[];      // [4][S] mn1 mx1 mn2 mx2 | double [6][S] zs, xp, lo, hi, l_all, h_all | int [2][S] NaN counts
+  double *lzs = (double *)(lacc + 4 * S), *xp = lzs + S, *lo = xp + S, *hi = lo + S, *lall = hi + S, *hall = lall + S;
+  int *lnan = (int *)(hall + S);
   __shared__ unsigned long long lbox[4];
   __shared__ int part[PREP_T];
   __shared__ int nvalid;
@@ -464,16 +464,30 @@ __global__ __launch_bounds__(PREP_T) void case_prepare_kernel(
     } else { l = dnan(); h = dnan(); }
     w[s] = l;
     w[S + s] = h;
+    lall[s] = l;
+    hall[s] = h;
   }
   __syncthreads();
-  if (tid == 0) {
+  // valid slices, compacted in order, by one wave (ballot + popcount per 64 slices): a single thread walking the S slices
+  // through global memory was a chain of S round trips -- most of the 23 us case_setup_kernel took
+  if (tid < 64) {
     int n = 0;
-    for (int s = 0; s < S; ++s) {
-      const double l = w[s], h = w[S + s];
-      if (l == l && h == h) { xp[n] = lzs[s]; lo[n] = l; hi[n] = h; ++n; }
+    for (int base = 0; base < S; base += 64) {
+      const int sl = base + tid;
+      double l = dnan(), h = dnan();
+      if (sl < S) { l = lall[sl]; h = hall[sl]; }
+      const bool ok = l == l && h == h;
+      const unsigned long long mask = __ballot(ok);
+      const int pos = n + __popcll(mask & ((1ULL << tid) - 1ULL));
+      if (ok) { xp[pos] = lzs[sl]; lo[pos] = l; hi[pos] = h; }
+      n += __popcll(mask);
     }
-    nvalid = n;
-    *(int *)(w + 2 * S + 2 * W) = n;
+    if (tid == 0) {
+      nvalid = n;
+      *(int *)(w + 2 * S + 2 * W) = n;
+    }
+  }
+  if (tid == 64) {
     // ---- cell grid: the same choice as case_setup_kernel
     const double ymn = dec(lbox[0]), ymx = dec(lbox[1]), zmn = dec(lbox[2]), zmx = dec(lbox[3]);
     const bool any = ymn <= ymx && zmn <= zmx;
@@ -842,7 +856,7 @@ int resample_launch(const double *pts, const int64_t *case_offsets, int ncase, i
   const int pblocks = cdiv(total, 256);
   // one block per case does everything before the search when the average case is a block's sweep (<= 32 Ki points) and the
   // slice tables fit its LDS; cfd_set_tuning(CFD_TUNE_RESAMPLE_FUSED, 0) keeps the multi-launch path (tests run both)
-  const size_t prep_lds = (size_t)8 * S * 8 + (size_t)2 * S * 4;
+  const size_t prep_lds = (size_t)10 * S * 8 + (size_t)2 * S * 4;
   const bool fused = tuning(CFD_TUNE_RESAMPLE_FUSED) != 0 && S <= 1024 && total / ncase <= 32768;
   if (fused) {
     if (int e_ = set_max_lds((const void *)case_prepare_kernel, (int)prep_lds)) return e_;

@@ -291,8 +291,8 @@ __device__ __forceinline__ void block_colsum8(const float (&acc)[8], int CV, flo
 #pragma unroll
   for (int i = 0; i < 8; ++i) red[tid][i] = acc[i];
   __syncthreads();
-  if (tid < CV * 8) {
-    const int cv = tid >> 3, i = tid & 7;
+  for (int e = tid; e < CV * 8; e += 256) {          // (C up to 2048: more channels than threads)
+    const int cv = e >> 3, i = e & 7;
     float s = 0.f;
     for (int r = cv; r < 256; r += CV) s += red[r][i];
     atomicAdd(dbias + cv * 8 + i, s);

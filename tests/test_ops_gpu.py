@@ -152,11 +152,17 @@ def test_conv_forward_pool2_keep(B, H, W, cin, cout, act):
     full = torch.full((B, H, W, cout + 64), 7.0, dtype=dtype, device=dev)
     pooled = torch.full((B, H // 2, W // 2, cout + 8), 5.0, dtype=dtype, device=dev)
     ops.conv_forward_pool2_keep(x, wp, bias, ops.CONV_K3S1, cout, code_act, full[..., 64:], pooled[..., :cout])
-    ops.set_tuning(ops.TUNE_IGEMM256, 1)      # the same kernel for the two-launch reference (small K: the heuristic takes the 128 x 128 one)
+    # the same kernel for the two-launch reference (the heuristics would take the 128 x 128 kernel for a small K, 128-wide
+    # n tiles for few tiles and the co-resident form for few K tiles: all other summation orders)
+    ops.set_tuning(ops.TUNE_IGEMM256, 1)
+    ops.set_tuning(ops.TUNE_NTILE, 256)
+    ops.set_tuning(ops.TUNE_PATCH, 1)
     try:
         y = ops.conv_forward(x, wp, bias, ops.CONV_K3S1, cout, act=code_act, split_k=1)
     finally:
         ops.set_tuning(ops.TUNE_IGEMM256, -1)
+        ops.set_tuning(ops.TUNE_NTILE, -1)
+        ops.set_tuning(ops.TUNE_PATCH, -1)
     two = ops.maxpool2(y)
     torch.cuda.synchronize()
     assert torch.equal(full[..., 64:], y)
@@ -204,10 +210,12 @@ def test_conv_forward_patch_staged(kind, B, H, W, cin, cout, ntile):
     if cout % ntile:
         pytest.skip("Cout is no multiple of this n tile")
     ops.set_tuning(ops.TUNE_NTILE, ntile)            # igemm256h_kernel / igemm128nh_kernel
+    ops.set_tuning(ops.TUNE_PATCH, 1)                # (1: never the co-resident form, which has its own test below)
     try:
         _igemm256_case(kind, B, H, W, cin, cout, 1, dtype, -1)
     finally:
         ops.set_tuning(ops.TUNE_NTILE, -1)
+        ops.set_tuning(ops.TUNE_PATCH, -1)
     x = q(rnd((B, H, W, cin), 1), dtype)
     bias = rnd((cout,), 3, 0.1)
     if kind == "convT":
@@ -223,6 +231,7 @@ def test_conv_forward_patch_staged(kind, B, H, W, cin, cout, ntile):
     wide[..., 64:64 + cin] = x.to(dev).to(dtype)
     ops.set_tuning(ops.TUNE_IGEMM256, 1)
     ops.set_tuning(ops.TUNE_NTILE, ntile)
+    ops.set_tuning(ops.TUNE_PATCH, 1)
     try:
         a = ops.conv_forward(wide[..., 64:64 + cin], wp, bias.to(dev), code, cout, out_dtype=torch.float32, split_k=1)
         ops.set_tuning(ops.TUNE_PATCH, 0)
