@@ -384,6 +384,56 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const double *__restri
 // with this case's counters in global memory (zeroed here, by the block that uses them).  Same arithmetic, same results;
 // used when the average case fits a block's sweep (the multi-launch path stays for huge cases, K blocks per case).
 constexpr int PREP_T = 1024;
+constexpr int PREP_LDS_CELLS = 8192;
+
+// count -> exclusive scan -> scatter for one case, by one block of PREP_T threads.  cntp (zeroed) / startp: the counters and
+// cell starts it works on (LDS or global); start_out (may be NULL = startp is already the global array) receives the starts.
+__device__ __forceinline__ void prepare_sort(int *cntp, int *startp, int *start_out, const CaseGrid &G, int ncell,
+                                             const double *__restrict__ pts, int64_t beg, int64_t end,
+                                             int *__restrict__ cell, double2 *__restrict__ syz, double2 *__restrict__ spu,
+                                             int *__restrict__ sidx, int *part) {
+  const int tid = threadIdx.x;
+  for (int64_t g = beg + tid; g < end; g += PREP_T) {
+    const int cy = bin1(pts[g * 5 + 1], G.y0, G.invy, G.hy, G.ny);
+    const int cz = bin1(pts[g * 5 + 2], G.z0, G.invz, G.hz, G.nz);
+    const int cc = cy * G.nz + cz;
+    cell[g] = cc;
+    atomicAdd(cntp + cc, 1);
+  }
+  __syncthreads();
+  const int per = (ncell + PREP_T - 1) / PREP_T;
+  const int a = tid * per < ncell ? tid * per : ncell, b = (a + per < ncell) ? a + per : ncell;
+  int sum = 0;
+  for (int i = a; i < b; ++i) sum += cntp[i];
+  part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < PREP_T; o <<= 1) {
+    const int v = (tid >= o) ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - sum;
+  for (int i = a; i < b; ++i) {
+    const int v = cntp[i];
+    startp[i] = run;
+    if (start_out) start_out[i] = run;
+    run += v;
+    cntp[i] = 0;
+  }
+  if (tid == PREP_T - 1) {
+    startp[ncell] = part[PREP_T - 1];
+    if (start_out) start_out[ncell] = part[PREP_T - 1];
+  }
+  __syncthreads();
+  for (int64_t g = beg + tid; g < end; g += PREP_T) {
+    const int cc = cell[g];
+    const int pos = startp[cc] + atomicAdd(cntp + cc, 1);
+    syz[beg + pos] = make_double2(pts[g * 5 + 1], pts[g * 5 + 2]);
+    spu[beg + pos] = make_double2(pts[g * 5 + 3], pts[g * 5 + 4]);
+    sidx[beg + pos] = (int)(g - beg);
+  }
+}
 
 __global__ __launch_bounds__(PREP_T) void case_prepare_kernel(
     const double *__restrict__ pts, const int64_t *__restrict__ offs, const double *__restrict__ zs, int S, double tol1,
@@ -522,47 +572,20 @@ __global__ __launch_bounds__(PREP_T) void case_prepare_kernel(
       w[2 * S + W + j] = h;
     }
   }
-  // ---- counting sort of the points by cell
+  // ---- counting sort of the points by cell: counters and prefix sums in LDS when the case's cells fit (PREP_LDS_CELLS),
+  // else in the global arrays; the cell starts go to global memory either way (the search reads them)
   CaseGrid G;
   G.ny = (int)gsh[0]; G.nz = (int)gsh[1]; G.y0 = gsh[2]; G.z0 = gsh[3]; G.invy = gsh[4]; G.invz = gsh[5]; G.hy = gsh[6]; G.hz = gsh[7];
-  for (int64_t g = beg + tid; g < end; g += PREP_T) {
-    const int cy = bin1(pts[g * 5 + 1], G.y0, G.invy, G.hy, G.ny);
-    const int cz = bin1(pts[g * 5 + 2], G.z0, G.invz, G.hz, G.nz);
-    const int cc = cy * G.nz + cz;
-    cell[g] = cc;
-    atomicAdd(c + cc, 1);
-  }
-  __syncthreads();
   const int ncell = G.ny * G.nz;
-  {
-    const int per = (ncell + PREP_T - 1) / PREP_T;
-    const int a = tid * per < ncell ? tid * per : ncell, b = (a + per < ncell) ? a + per : ncell;
-    int sum = 0;
-    for (int i = a; i < b; ++i) sum += c[i];
-    part[tid] = sum;
+  int *lc = lnan + 2 * S;                       // [PREP_LDS_CELLS] counts / fill, then [PREP_LDS_CELLS + 1] starts
+  int *ls = lc + PREP_LDS_CELLS;
+  const bool in_lds = ncell <= PREP_LDS_CELLS;  // (uniform)
+  if (in_lds) {
+    for (int i = tid; i < ncell; i += PREP_T) lc[i] = 0;
     __syncthreads();
-    for (int o = 1; o < PREP_T; o <<= 1) {
-      const int v = (tid >= o) ? part[tid - o] : 0;
-      __syncthreads();
-      part[tid] += v;
-      __syncthreads();
-    }
-    int run = part[tid] - sum;
-    for (int i = a; i < b; ++i) {
-      const int v = c[i];
-      st[i] = run;
-      run += v;
-      c[i] = 0;
-    }
-    if (tid == PREP_T - 1) st[ncell] = part[PREP_T - 1];
-  }
-  __syncthreads();
-  for (int64_t g = beg + tid; g < end; g += PREP_T) {
-    const int cc = cell[g];
-    const int pos = st[cc] + atomicAdd(c + cc, 1);
-    syz[beg + pos] = make_double2(pts[g * 5 + 1], pts[g * 5 + 2]);
-    spu[beg + pos] = make_double2(pts[g * 5 + 3], pts[g * 5 + 4]);
-    sidx[beg + pos] = (int)(g - beg);
+    prepare_sort(lc, ls, st, G, ncell, pts, beg, end, cell, syz, spu, sidx, part);
+  } else {
+    prepare_sort(c, st, (int *)nullptr, G, ncell, pts, beg, end, cell, syz, spu, sidx, part);
   }
 }
 
@@ -856,7 +879,7 @@ int resample_launch(const double *pts, const int64_t *case_offsets, int ncase, i
   const int pblocks = cdiv(total, 256);
   // one block per case does everything before the search when the average case is a block's sweep (<= 32 Ki points) and the
   // slice tables fit its LDS; cfd_set_tuning(CFD_TUNE_RESAMPLE_FUSED, 0) keeps the multi-launch path (tests run both)
-  const size_t prep_lds = (size_t)10 * S * 8 + (size_t)2 * S * 4;
+  const size_t prep_lds = (size_t)10 * S * 8 + (size_t)2 * S * 4 + (size_t)(2 * PREP_LDS_CELLS + 1) * 4;
   const bool fused = tuning(CFD_TUNE_RESAMPLE_FUSED) != 0 && S <= 1024 && total / ncase <= 32768;
   if (fused) {
     if (int e_ = set_max_lds((const void *)case_prepare_kernel, (int)prep_lds)) return e_;
