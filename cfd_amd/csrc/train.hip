@@ -490,25 +490,20 @@ __global__ __launch_bounds__(256) void field_loss_kernel(const float *__restrict
 }
 
 // ---- Adam (Keras form): m += (g-m)(1-b1); v += (g^2-v)(1-b2); w -= alpha*m/(sqrt(v)+eps) ---------
-// Two independent 16-B vectors per stream and thread per iteration (eight loads in flight before the first use) on a bounded
-// grid: 7 x 4 B + 2 B per parameter is all this kernel does, so it lives on bytes in flight.
 template <typename TC>
-__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
+__global__ void adam_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
                             float *__restrict__ v, TC *__restrict__ wc, int64_t n, float alpha, float b1, float b2,
                             float eps, float gscale) {
   const int64_t n4 = n >> 2;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const float c1 = 1.f - b1, c2 = 1.f - b2;
-  auto upd = [&](f32x4 &wv, const f32x4 &gv, f32x4 &mv, f32x4 &vv) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 wv = ((f32x4 *)w)[i], gv = ((const f32x4 *)g)[i], mv = ((f32x4 *)m)[i], vv = ((f32x4 *)v)[i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gk = gv[k] * gscale;
-      mv[k] += (gk - mv[k]) * c1;
-      vv[k] += (gk * gk - vv[k]) * c2;
+      mv[k] += (gk - mv[k]) * (1.f - b1);
+      vv[k] += (gk * gk - vv[k]) * (1.f - b2);
       wv[k] -= (mv[k] * alpha) / (sqrtf(vv[k]) + eps);
     }
-  };
-  auto put = [&](int64_t i, const f32x4 &wv, const f32x4 &mv, const f32x4 &vv) {
     ((f32x4 *)w)[i] = wv; ((f32x4 *)m)[i] = mv; ((f32x4 *)v)[i] = vv;
     if (wc) {
       if constexpr (sizeof(TC) == 2) {
@@ -516,21 +511,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const 
         ((bf16x4 *)wc)[i] = o;
       }
     }
-  };
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + stride < n4; i += 2 * stride) {
-    const int64_t j = i + stride;
-    f32x4 w0 = ((f32x4 *)w)[i], g0 = ((const f32x4 *)g)[i], m0 = ((f32x4 *)m)[i], v0 = ((f32x4 *)v)[i];
-    f32x4 w1 = ((f32x4 *)w)[j], g1 = ((const f32x4 *)g)[j], m1 = ((f32x4 *)m)[j], v1 = ((f32x4 *)v)[j];
-    upd(w0, g0, m0, v0);
-    upd(w1, g1, m1, v1);
-    put(i, w0, m0, v0);
-    put(j, w1, m1, v1);
-  }
-  if (i < n4) {
-    f32x4 w0 = ((f32x4 *)w)[i], g0 = ((const f32x4 *)g)[i], m0 = ((f32x4 *)m)[i], v0 = ((f32x4 *)v)[i];
-    upd(w0, g0, m0, v0);
-    put(i, w0, m0, v0);
   }
 }
 
@@ -985,9 +965,9 @@ extern "C" int cfd_adam_step(float *w, const float *g, float *m, float *v, void 
                              void *stream) {
   CFD_REQUIRE(w && g && m && v && n > 0 && n % 4 == 0, "bad arguments (n must be a multiple of 4)");
   hipStream_t st = (hipStream_t)stream;
-  // bounded grid (16 blocks per CU), each thread walking pairs of vectors; CFD_ADAM_GRID=0 restores one vector per thread (A/B)
-  static const int adam_cap = [] { const char *e = getenv("CFD_ADAM_GRID"); return e ? atoi(e) : 4096; }();
-  const int blocks = adam_cap > 0 ? grid_for(n / 4, adam_cap) : grid_for(n / 4);
+  // one 16-B vector per stream and thread, as many blocks as that takes: measured against a bounded grid with two vectors in
+  // flight per thread (scripts/micro/adam_bw.py, 128 M parameters): 737 us = 5.46 TB/s against 804-946 us = 4.3-5.0 TB/s
+  const int blocks = grid_for(n / 4);
   if (w_compute && compute_dtype == CFD_BF16)
     hipLaunchKernelGGL(adam_kernel<bf16>, dim3(blocks), dim3(256), 0, st, w, g, m, v, (bf16 *)w_compute, n, alpha,
                        beta1, beta2, eps, grad_scale);

@@ -17,9 +17,10 @@ Same names, same argument meaning, numpy NHWC fp32 in / numpy out, Python except
 Everything below the method calls runs on the HIP kernels (cfd_amd.nets / cfd_amd.trainer).
 
 Environment switches:
-  CFD_AMD_DTYPE = bf16 | fp32   arithmetic type of the MFMA kernels.  Default bf16 (north_star's target arithmetic: fp32
-                                accumulation, outputs within 2e-2 of the fp32 oracle); fp32 is the reference's own
-                                arithmetic (Keras float32), within 1e-4 of the oracle, ~2.5x slower.
+  CFD_AMD_DTYPE = fp32 | bf16   arithmetic type of the MFMA kernels.  Default fp32: the reference's own arithmetic (Keras
+                                float32; exact-f32 MFMA, within 1e-4 of the oracle) -- a drop-in gives the reference's
+                                numbers unless asked otherwise.  bf16 (north_star's target arithmetic: bf16 operands, fp32
+                                accumulation, outputs within 2e-2 of the fp32 oracle) is ~2.7x faster at batch 128.
 """
 from __future__ import annotations
 
@@ -37,7 +38,7 @@ from . import h5, keras_h5, nets, ops, trainer
 
 def _dtype() -> torch.dtype:
     return {"bf16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32}[
-        os.environ.get("CFD_AMD_DTYPE", "bf16").lower()]
+        os.environ.get("CFD_AMD_DTYPE", "fp32").lower()]
 
 
 GRAPH_MAX_BATCH = 8     # largest batch whose predict is replayed as one captured HIP graph (CFD_AMD_GRAPHS=0 turns it off)

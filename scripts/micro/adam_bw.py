@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """HBM rate of cfd_adam_step on a U-generator-sized range (128 M parameters, bf16 shadow): 30 B per parameter.
-    CFD_ADAM_GRID=<blocks cap | 0 = one vector per thread> python scripts/micro/adam_bw.py"""
+    python scripts/micro/adam_bw.py   (round 3: one vector per thread 737 us = 5.46 TB/s; bounded grids were slower)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
