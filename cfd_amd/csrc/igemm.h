@@ -100,6 +100,9 @@ bool igemm256_eligible(const IgemmParams &p, int dtype);
 int igemm256_launch(const IgemmParams &p, int dtype, hipStream_t st);
 int igemm256_block_count(const IgemmParams &p);
 int igemm256_ntile(const IgemmParams &p);
+// igemm256.hip: Cout = 64 (mod 128) on the co-resident patch kernel's 64-wide n tile
+bool igemm_n64_eligible(const IgemmParams &p, int dtype);
+int igemm_n64_launch(const IgemmParams &p, hipStream_t st);
 // igemm256h.hip: does the patch-staged kernel take this launch (p prepared as by igemm256_launch)?
 bool igemm256h_eligible(const IgemmParams &p, int dtype, int ntile);
 

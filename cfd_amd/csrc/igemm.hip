@@ -419,6 +419,7 @@ extern "C" int cfd_conv_suggest_split_k(const cfd_conv_desc *d) {
   t.split_k = 1;
   IgemmParams p;
   if (fill_params(&t, p) != CFD_OK) return 1;
+  if (igemm_n64_eligible(p, d->dtype)) return 1;
   if (use_igemm256(p, d->dtype)) return split_k_256(p);
   const int ktiles = p.ntaps * p.cpt;
   int s = 1;
@@ -456,7 +457,10 @@ static int conv_forward_impl(const cfd_conv_desc *d, const void *x, const void *
   }
   hipStream_t st = (hipStream_t)stream;
   const size_t shmem = 2 * STAGE_BYTES;
-  if (use_igemm256(p, d->dtype)) {
+  if (igemm_n64_eligible(p, d->dtype)) {
+    rc = igemm_n64_launch(p, st);
+    if (rc != CFD_OK) return rc;
+  } else if (use_igemm256(p, d->dtype)) {
     rc = igemm256_launch(p, d->dtype, st);
     if (rc != CFD_OK) return rc;
   } else if (d->dtype == CFD_BF16) {

@@ -1178,6 +1178,26 @@ int igemm256_block_count(const IgemmParams &p) {
   return cdiv(p.M, 256) * (p.Cout / igemm256_ntile(p)) * p.nclass * p.split_k;
 }
 
+// Cout = 64 (mod 128), bf16, patch-eligible, no split-K: the co-resident patch kernel with a 64-wide n tile (the only kernel
+// that does not spend half its MFMAs on an empty half tile there -- DeltaP g3's data gradient, 128 -> 64 channels)
+bool igemm_n64_eligible(const IgemmParams &pin, int dtype) {
+  if (dtype != CFD_BF16 || pin.Cout % 128 != 64 || pin.split_k != 1 || pin.pool || pin.stat_sum) return false;
+  if (tuning(CFD_TUNE_PATCH) == 0 || tuning(CFD_TUNE_IGEMM256) == 0 || tuning(CFD_TUNE_IGEMM256_PD) >= 0) return false;
+  if (pin.Cin % 64 != 0 || pin.ntaps > 16 || x_bytes(pin, 2) >= (1LL << 31) || w_bytes(pin, 2) >= (1LL << 31)) return false;
+  return igemm256h_eligible(pin, dtype, 64) && (int64_t)cdiv(pin.M, 256) * (pin.Cout / 64) * pin.nclass >= 256;
+}
+
+int igemm_n64_launch(const IgemmParams &pin, hipStream_t st) {
+  IgemmParams p = pin;
+  CFD_REQUIRE(igemm_n64_eligible(p, CFD_BF16), "64-wide co-resident kernel: shape not eligible");
+  p.mtiles = cdiv(p.M, 256);
+  p.ntiles = p.Cout / 64;
+  p.nblocks = p.mtiles * p.ntiles * p.nclass;
+  const int co = tuning(CFD_TUNE_CLASS_ORDER);
+  const int cls_fast = p.nclass > 1 && (co < 0 ? x_bytes(p, 2) > w_bytes(p, 2) : co == 1);
+  return igemm256h_launch(p, 64, (unsigned)x_bytes(p, 2), (unsigned)w_bytes(p, 2), cls_fast, 0, st, true);
+}
+
 int igemm256_launch(const IgemmParams &pin, int dtype, hipStream_t st) {
   const int es = dtype == CFD_BF16 ? 2 : 4;
   Igemm256Params P;

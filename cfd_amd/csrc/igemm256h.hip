@@ -776,8 +776,13 @@ __device__ __forceinline__ HaloChunk halo_chunk_c(int g, int c, int cin2, int wi
   }
 }
 
-template <int NT, bool S2 = false>
+// NW = 128: waves 2 (n) x 4 (m), a wave owns 64 n rows and tile rows 2 wc, 2 wc + 1.  NW = 64 (Cout = 64 mod 128: DeltaP g3's
+// data gradient): waves 1 x 8, a wave owns all 64 n rows and tile row wc; the weight stage keeps its 128-row frame, waves 4-7
+// issue their weight load out of range (zero fill into rows no one reads) so that every wave's vmcnt count stays the same.
+template <int NT, bool S2 = false, int NW = 128>
 __global__ __launch_bounds__(512, 4) void igemm128c_kernel(IgemmHaloParams P) {
+  constexpr int MJ = NW == 128 ? 4 : 2;        // 16-pixel fragments per wave
+  constexpr int NWC = NW == 128 ? 4 : 8;       // waves along m
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   using G = HaloGeoC<NT, S2>;
   const IgemmParams &p = P.g;
@@ -786,11 +791,12 @@ __global__ __launch_bounds__(512, 4) void igemm128c_kernel(IgemmHaloParams P) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
+  const int grp = wave >> 2;                                // ping-pong group: waves 4-7 run one barrier behind
+  const int wr = NW == 128 ? wave >> 2 : 0, wc = NW == 128 ? wave & 3 : wave;
 
   const HaloTile tile = halo_tile(P);
   const int cls = tile.cls, ph = cls >> 1, pw = cls & 1;
-  const int n0 = tile.nt * 128;
+  const int n0 = tile.nt * NW;
   const int b = tile.b, ty0 = tile.ty0, tx0 = tile.tx0;
   const int cpt = p.cpt;                                    // chunks of 32 channels per group (host: Cin / 32)
   const int ncc = S2 ? 4 * cpt : cpt;
@@ -817,7 +823,7 @@ __global__ __launch_bounds__(512, 4) void igemm128c_kernel(IgemmHaloParams P) {
   // ---- staging geometry: piece = 16 rows x 64 B; lane -> row lane >> 2, physical chunk lane & 3 = logical chunk ^ ((row >> 1) & 3)
   const int lrow = lane >> 2;
   const int kc = (lane & 3) ^ ((lrow >> 1) & 3);
-  const unsigned avoff = (unsigned)(((n0 + wave * 16 + lrow) * p.Kw + kc * 8) * 2);
+  const unsigned avoff = (NW == 128 || wave < 4) ? (unsigned)(((n0 + wave * 16 + lrow) * p.Kw + kc * 8) * 2) : OOB;
   unsigned pvoff[G::PPW];
   {
     const int py0 = ty0 + P.dymin[cls], px0 = tx0 + P.dxmin[cls];
@@ -843,13 +849,13 @@ __global__ __launch_bounds__(512, 4) void igemm128c_kernel(IgemmHaloParams P) {
   // ---- fragment read offsets (row r of a stage / pixel pp of the patch at r * 64, chunk fq at (fq ^ ((r >> 1) & 3)) * 16)
   const int fr = lane & 15, fq = lane >> 4;
   const char *const ard = lds + wr * 64 * 64 + fr * 64 + ((fq ^ ((fr >> 1) & 3)) << 4);
-  const int L0 = 2 * wc * H_PW + fr;
+  const int L0 = (NW == 128 ? 2 * wc : wc) * H_PW + fr;
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][MJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (p.bias) {   // the n tile's bias rides to LDS with the first loads (lanes 32-63 fetch the next tile's or zeros: unused)
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, p.Cout * 4, 0x00020000);
@@ -861,9 +867,9 @@ __global__ __launch_bounds__(512, 4) void igemm128c_kernel(IgemmHaloParams P) {
   issueA(1, (unsigned)(wto[1 % NT] + (1 / NT ? nxt.a : cur.a)));
   hwaitc<1>();
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
 
-  frag_t a[4], bf[4];
+  frag_t a[4], bf[MJ];
   int stg = 0;   // ring stage of the current K tile
 
   auto ktile = [&](auto tc, int c) {
@@ -888,8 +894,10 @@ __global__ __launch_bounds__(512, 4) void igemm128c_kernel(IgemmHaloParams P) {
     for (int i = 0; i < 4; ++i) a[i] = *(const frag_t *)(ard + st * C_ST + i * 1024);
     bf[0] = *(const frag_t *)(b0p);
     bf[1] = *(const frag_t *)(b0p + 1024);
-    bf[2] = *(const frag_t *)(b1p);
-    bf[3] = *(const frag_t *)(b1p + 1024);
+    if constexpr (MJ == 4) {
+      bf[2] = *(const frag_t *)(b1p);
+      bf[3] = *(const frag_t *)(b1p + 1024);
+    }
 #pragma unroll
     for (int jj = 0; jj < NP; ++jj) issueP(J0 + jj, pst ^ 1, sp);
     issueA(st2, sa2);
@@ -901,7 +909,7 @@ __global__ __launch_bounds__(512, 4) void igemm128c_kernel(IgemmHaloParams P) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = mma(a[i], bf[j], acc[i][j]);
+      for (int j = 0; j < MJ; ++j) acc[i][j] = mma(a[i], bf[j], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -917,12 +925,12 @@ __global__ __launch_bounds__(512, 4) void igemm128c_kernel(IgemmHaloParams P) {
     chunk_step();
     nxt = halo_chunk_c<S2>(ng, nc, cin2, p.Wi, ldx2);
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();
+  if (grp == 0) __builtin_amdgcn_s_barrier();
   hwait<0>();   // the tail loads must not outlive the workgroup's LDS allocation
 
   if (p.stat_sum) {   // fused BatchNorm statistics, as in igemm128nh_kernel
     __syncthreads();
-    float *part = (float *)lds;   // [2][4 wc][128 n]
+    float *part = (float *)lds;   // [2][NWC wc][NW n]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int nl = wr * 64 + i * 16 + fq * 4;
@@ -932,7 +940,7 @@ __global__ __launch_bounds__(512, 4) void igemm128c_kernel(IgemmHaloParams P) {
       for (int r = 0; r < 4; ++r) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < MJ; ++j) {
           const float v = acc[i][j][r] + bv[r];
           t1 += v;
           t2 = fmaf(v, v, t2);
@@ -940,16 +948,18 @@ __global__ __launch_bounds__(512, 4) void igemm128c_kernel(IgemmHaloParams P) {
         t1 = row16_sum(t1);
         t2 = row16_sum(t2);
         if (fr == 0) {
-          part[(0 * 4 + wc) * 128 + nl + r] = t1;
-          part[(1 * 4 + wc) * 128 + nl + r] = t2;
+          part[(0 * NWC + wc) * NW + nl + r] = t1;
+          part[(1 * NWC + wc) * NW + nl + r] = t2;
         }
       }
     }
     __syncthreads();
-    if (tid < 256) {
-      const int which = tid >> 7, c = tid & 127;
-      const float *pp = part + which * 512 + c;
-      const float tot = pp[0] + pp[128] + pp[256] + pp[384];
+    if (tid < 2 * NW) {
+      const int which = tid / NW, c = tid - which * NW;
+      const float *pp = part + which * NWC * NW + c;
+      float tot = 0.f;
+#pragma unroll
+      for (int k2 = 0; k2 < NWC; ++k2) tot += pp[k2 * NW];
       atomicAdd((which ? p.stat_sq : p.stat_sum) + (size_t)b * p.Cout + n0 + c, tot);
     }
   }
@@ -959,8 +969,8 @@ __global__ __launch_bounds__(512, 4) void igemm128c_kernel(IgemmHaloParams P) {
   auto direct_epi = [&](auto mode_c) {
     constexpr int MODE = decltype(mode_c)::value;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int local = wc * 64 + j * 16 + fr;
+    for (int j = 0; j < MJ; ++j) {
+      const int local = wc * (16 * MJ) + j * 16 + fr;
       const int qy = ty0 + (local >> 5), qx = tx0 + (local & 31);
       const int64_t opix = p.kind == CFD_CONVT_K4S2 ? ((int64_t)b * p.Ho + 2 * qy + ph) * p.Wo + 2 * qx + pw
                                                      : ((int64_t)b * p.Hq + qy) * p.Wq + qx;
@@ -1004,11 +1014,13 @@ int igemm256h_launch(const IgemmParams &pin, int ntile, unsigned xbytes, unsigne
   memset(&P, 0, sizeof(P));
   P.g = pin;
   if (coresident) {
-    CFD_REQUIRE(ntile == 128 && !pin.pool && pin.Cin % 32 == 0, "co-resident patch kernel: 128-wide n tiles, no pooled epilogue");
+    CFD_REQUIRE((ntile == 128 || ntile == 64) && !pin.pool && pin.Cin % 32 == 0,
+                "co-resident patch kernel: 128- or 64-wide n tiles, no pooled epilogue");
     P.g.cpt = pin.Cin / 32;      // this kernel's chunks are 32 channels
   }
   const IgemmParams &p = P.g;
-  CFD_REQUIRE((ntile == 128 || ntile == 256) && igemm256h_eligible(p, CFD_BF16, ntile) && p.ntiles * ntile == p.Cout,
+  CFD_REQUIRE((ntile == 128 || ntile == 256 || (ntile == 64 && coresident)) && igemm256h_eligible(p, CFD_BF16, ntile) &&
+                  p.ntiles * ntile == p.Cout,
               "patch-staged kernel: shape not eligible");
   P.xbytes = xbytes; P.wbytes = wbytes; P.cls_fast = cls_fast; P.stage_out = stage_out;
   P.tpr = p.Wq / H_TW;
@@ -1052,7 +1064,11 @@ int igemm256h_launch(const IgemmParams &pin, int ntile, unsigned xbytes, unsigne
   typedef HaloGeo<4, true> GeoS2;
   typedef HaloGeo3<4, true> Geo3S2;
   typedef HaloGeoC<4, true> GeoCS2;
-  if (coresident) {
+  if (coresident && ntile == 64) {
+    if (s2) CFD_LAUNCH_H((igemm128c_kernel<4, true, 64>), GeoCS2);
+    else if (p.ntaps == 9) CFD_LAUNCH_H((igemm128c_kernel<9, false, 64>), HaloGeoC<9>);
+    else CFD_LAUNCH_H((igemm128c_kernel<4, false, 64>), HaloGeoC<4>);
+  } else if (coresident) {
     if (s2) CFD_LAUNCH_H((igemm128c_kernel<4, true>), GeoCS2);
     else if (p.ntaps == 9) CFD_LAUNCH_H(igemm128c_kernel<9>, HaloGeoC<9>);
     else CFD_LAUNCH_H(igemm128c_kernel<4>, HaloGeoC<4>);

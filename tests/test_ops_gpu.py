@@ -304,6 +304,46 @@ def test_conv_forward_patch_coresident(kind, B, H, W, cin, cout):
     assert relerr(stats[1].cpu() / n, (b.float() ** 2).mean(dim=(1, 2)).cpu()) <= 2e-5
 
 
+@pytest.mark.parametrize("kind,B,H,W,cin,cout", [
+    ("k3s1", 8, 32, 256, 128, 64),      # DeltaP g3's data gradient: 128 -> 64 channels, 256 tiles
+    ("convT", 4, 32, 128, 64, 64),      # four sub-pixel classes x 64 tiles
+    ("k4s2", 8, 64, 256, 64, 192),      # three 64-wide n tiles, stride-2 parity groups
+])
+def test_conv_forward_cout_64_mod_128(kind, B, H, W, cin, cout):
+    """Cout = 64 (mod 128) takes the co-resident patch kernel's 64-wide n tile (igemm128c_kernel<.., 64>) once the launch
+    has at least 256 tiles; against the oracle and against the 128 x 128 kernel (CFD_TUNE_PATCH = 0)"""
+    from cfd_amd import ops
+    dtype, dev = torch.bfloat16, "cuda"
+    x = q(rnd((B, H, W, cin), 1), dtype)
+    bias = rnd((cout,), 3, 0.1)
+    if kind == "convT":
+        wk = q(rnd((4, 4, cout, cin), 2, 0.05), dtype)
+        ref = O.conv2d_transpose_same(x, wk, bias)
+        wp, code = ops.pack_convT_weight(wk.to(dev), dtype), ops.CONVT_K4S2
+    elif kind == "k4s2":
+        wk = q(rnd((4, 4, cin, cout), 2, 0.05), dtype)
+        ref = O.conv2d_same(x, wk, bias, 2)
+        wp, code = ops.pack_conv_weight(wk.to(dev), dtype), ops.CONV_K4S2
+    else:
+        wk = q(rnd((3, 3, cin, cout), 2, 0.05), dtype)
+        ref = O.conv2d_same(x, wk, bias, 1)
+        wp, code = ops.pack_conv_weight(wk.to(dev), dtype), ops.CONV_K3S1
+    xd = x.to(dev).to(dtype)
+    a = ops.conv_forward(xd, wp, bias.to(dev), code, cout, out_dtype=torch.float32, split_k=1)
+    buf = torch.zeros(tuple(ref.shape[:-1]) + (cout + 64,), dtype=dtype, device=dev)
+    ops.conv_forward(xd, wp, bias.to(dev), code, cout, act=ops.ACT_LEAKY, out=buf[..., 64:], split_k=1)
+    ops.set_tuning(ops.TUNE_PATCH, 0)
+    try:
+        b = ops.conv_forward(xd, wp, bias.to(dev), code, cout, out_dtype=torch.float32, split_k=1)
+    finally:
+        ops.set_tuning(ops.TUNE_PATCH, -1)
+    torch.cuda.synchronize()
+    assert relerr(a.cpu(), ref) <= 1e-4
+    assert relerr(a.cpu(), b.cpu()) <= 1e-5 and not torch.equal(a, b)      # another kernel, another summation order
+    assert relerr(buf[..., 64:].float().cpu(), O.leaky(ref)) <= TOL[dtype]
+    assert float(buf[..., :64].float().abs().max()) == 0.0
+
+
 def _igemm256_case(kind, B, H, W, cin, cout, split_k, dtype, pd):
     """the 256x256 ping-pong kernel (igemm256.hip; bf16 and exact-f32 MFMA), forced on, against the oracle; bias +
     LeakyReLU fused, output written into a channel slice of a wider buffer"""
