@@ -31,6 +31,8 @@ struct WgradParams {
   unsigned long long magicW, magicHW;  // exact division of m by Wm and by Hm*Wm: q = (m * magic) >> (32 + shift)
   int shiftW, shiftHW;
   int nblocks;
+  float *slab;          // split-M partial results [split_m][Cout][taps][Cin], summed by wgrad_slab_reduce in a fixed order; NULL = atomics
+  int64_t dw_elems;
 };
 
 __device__ __attribute__((aligned(16))) const unsigned int g_zero_page_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -205,9 +207,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wco + i * 16 + fq * 4 + r;
         if (co >= p.Cout) continue;
-        float *dst = p.dw + ((int64_t)co * p.ntaps + wtap) * p.Cin + ci;
-        if (p.split_m > 1) atomicAdd(dst, acc[i][j][r]);
-        else *dst = acc[i][j][r];
+        const int64_t e = ((int64_t)co * p.ntaps + wtap) * p.Cin + ci;
+        if (p.slab) p.slab[(int64_t)sm * p.dw_elems + e] = acc[i][j][r];
+        else if (p.split_m > 1) atomicAdd(p.dw + e, acc[i][j][r]);
+        else p.dw[e] = acc[i][j][r];
       }
     }
 }
@@ -270,6 +273,11 @@ static int conv_wgrad_impl(const cfd_conv_desc *d, const void *x, const void *dy
   const int64_t nb = (int64_t)p.cotiles * p.citiles * p.tap_groups * p.split_m;
   CFD_REQUIRE(nb < (1LL << 31), "grid too large");
   p.nblocks = (int)nb;
+  // split-M partial results as slabs when the caller brought the workspace for them (cfd_conv_wgrad_workspace_bytes): a small
+  // weight tensor with a long reduction (DeltaP g3: 73 728 weights, 524 288 pixels at B = 64, 128 slices) otherwise takes
+  // ~10 M fp32 atomics onto 73 K addresses
+  p.dw_elems = (int64_t)d->Cout * p.ntaps * d->Cin;
+  p.slab = (p.split_m > 1 && workspace && p.dw_elems % 4 == 0) ? (float *)workspace : nullptr;
   hipStream_t st = (hipStream_t)stream;
   const size_t shmem = 2 * W_STAGE_BYTES;
   if (d->dtype == CFD_BF16) {
@@ -280,7 +288,17 @@ static int conv_wgrad_impl(const cfd_conv_desc *d, const void *x, const void *dy
     hipLaunchKernelGGL(wgrad_kernel<float>, dim3(p.nblocks), dim3(256), shmem, st, p);
   }
   CFD_LAUNCH_CHECK();
+  if (p.slab) return wgrad_slab_reduce_launch(p.slab, dw, p.dw_elems / 4, p.split_m, st);
   return CFD_OK;
+}
+
+// bytes of split-M slabs the 128 x 128 kernel can use (0: none -- atomics): small weight tensors only
+static int64_t wgrad128_slab_bytes(const cfd_conv_desc *d, int split_m) {
+  if (split_m <= 1) return 0;
+  const int ntaps = d->kind == CFD_CONV_K3S1 ? 9 : (d->kind == CFD_DENSE ? 1 : 16);
+  const int64_t elems = (int64_t)d->Cout * ntaps * d->Cin;
+  const int64_t bytes = elems * 4 * split_m;
+  return (elems % 4 == 0 && bytes <= (256LL << 20)) ? bytes : 0;
 }
 
 extern "C" int cfd_conv_wgrad(const cfd_conv_desc *d, const void *x, const void *dy, float *dw, int split_m,
@@ -296,7 +314,7 @@ extern "C" int cfd_conv_wgrad_ws(const cfd_conv_desc *d, const void *x, const vo
 extern "C" int64_t cfd_conv_wgrad_workspace_bytes(const cfd_conv_desc *d, int split_m) {
   Wgrad256Params p2;
   if (d && wgrad256_selected(d, p2)) return wgrad256_workspace_bytes(p2, split_m);
-  return 0;
+  return d ? wgrad128_slab_bytes(d, split_m) : 0;
 }
 
 extern "C" int cfd_conv_wgrad_suggest_split(const cfd_conv_desc *d) {

@@ -25,6 +25,8 @@ bool wgrad256_plan(const cfd_conv_desc *d, Wgrad256Params &p);
 bool wgrad256_selected(const cfd_conv_desc *d, Wgrad256Params &p);
 int wgrad256_suggest_split(const Wgrad256Params &p);
 int64_t wgrad256_workspace_bytes(const Wgrad256Params &p, int split_m);
+// dw[i] = sum over s of slab[s][i], i < 4 * n4, in a fixed order (shared with wgrad.hip's 128 x 128 kernel)
+int wgrad_slab_reduce_launch(const float *slab, float *dw, int64_t n4, int split, hipStream_t st);
 int wgrad256_launch(Wgrad256Params &p, const void *x, const void *dy, float *dw, int split_m, float *workspace,
                     hipStream_t st);
 

@@ -265,6 +265,13 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float *__r
   }
 }
 
+int wgrad_slab_reduce_launch(const float *slab, float *dw, int64_t n4, int split, hipStream_t st) {
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, dw, n4, split);
+  CFD_LAUNCH_CHECK();
+  return CFD_OK;
+}
+
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
