@@ -132,7 +132,17 @@ __device__ __forceinline__ HaloChunk halo_chunk(int g, int c, int cin2, int wi, 
   }
 }
 
-template <int NT, bool S2 = false>
+// OP ("one phase", round 3): ONE barrier pair and one cluster of 64 MFMAs per K tile instead of two of 32.  The fragment
+// registers stay 64: the cluster starts with the A0 half tile's fragments and re-fills each A register quad with the A1
+// half tile's fragment as soon as its eight MFMAs have issued (LDS reads inside the cluster, ~a K tile ahead of their
+// use).  That keeps the A1 slot of a stage under read until the END of a group's cluster, so the LDS-DMA duty is split
+// by group: waves 0-3 load the A0 half tile of K tile k + 1 (whose old content both groups finished in their pre-cluster
+// parts), waves 4-7 -- one barrier behind, i.e. in their pre-cluster part while waves 0-3 run cluster k -- load the A1
+// half tile (whose old content waves 0-3 finished with cluster k - 1 and they themselves with theirs).  Every wave waits
+// for its own loads (vmcnt(0)) AFTER its cluster, before the closing barrier: the loads have a pre-cluster part and a whole
+// cluster (~1 500 cycles) to land.  Barrier intervals double (1 024 MFMA cycles against the ~190 cycles of hand-over that
+// kept the two-phase loop at 0.70-0.73 MFMA-busy).
+template <int NT, bool S2 = false, bool OP = false>
 __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   using G = HaloGeo<NT, S2>;
@@ -179,8 +189,12 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
   const int chunk = (lane & 7) ^ lrow;
   unsigned avoff[4];   // weights: row (n0 + half*128 + piece*64 + wave*8 + lrow), r = half*2 + piece
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-    avoff[r] = (unsigned)(((n0 + (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow) * p.Kw + chunk * 8) * 2);
+  for (int r = 0; r < 4; ++r) {
+    if constexpr (OP)   // group g = wave >> 2 loads half tile g: pieces (wave & 3) * 4 + r, rows piece * 8 + lrow
+      avoff[r] = (unsigned)(((n0 + wr * 128 + ((wave & 3) * 4 + r) * 8 + lrow) * p.Kw + chunk * 8) * 2);
+    else
+      avoff[r] = (unsigned)(((n0 + (r >> 1) * 128 + (r & 1) * 64 + wave * 8 + lrow) * p.Kw + chunk * 8) * 2);
+  }
   unsigned pvoff[G::PPW];   // patch: load j of this wave covers patch pixels q*8 .. q*8+7, q = min(j*8 + wave, NPI-1)
   {
     const int py0 = ty0 + P.dymin[cls], px0 = tx0 + P.dxmin[cls];
@@ -209,6 +223,11 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
     const int q = min(j * 8 + wave, G::NPI - 1);
     bload16(xrs, pvoff[j], sp, lds + H_ABYTES + pst * G::PATCH + q * 1024);
   };
+  auto issueHalf = [&](int st, unsigned sa) {        // OP: this wave's four pieces of its group's half tile
+    char *dst = lds + st * (2 * HT_BYTES) + wr * HT_BYTES + (wave & 3) * 4096;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bload16(wrs, avoff[r], sa, dst + r * 1024);
+  };
 
   // ---- fragment read offsets
   const int fr = lane & 15, fq = lane >> 4;
@@ -234,10 +253,15 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
   }
 #pragma unroll
   for (int j = 0; j < G::PPW; ++j) issueP(j, 0, (unsigned)cur.p);
-  issueA0(0, (unsigned)(wto[0] + cur.a));
-  issueA1(0, (unsigned)(wto[0] + cur.a));
-  issueA0(1, (unsigned)(wto[1 % NT] + (1 / NT ? nxt.a : cur.a)));
-  hwait<4>();
+  if constexpr (OP) {
+    issueHalf(0, (unsigned)(wto[0] + cur.a));
+    hwait<0>();
+  } else {
+    issueA0(0, (unsigned)(wto[0] + cur.a));
+    issueA1(0, (unsigned)(wto[0] + cur.a));
+    issueA0(1, (unsigned)(wto[1 % NT] + (1 / NT ? nxt.a : cur.a)));
+    hwait<4>();
+  }
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // second group runs one barrier behind
 
@@ -269,6 +293,60 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
     const unsigned sa2 = (unsigned)(wto[t2] + (k2 ? nxt.a : cur.a));
     const unsigned sp = (unsigned)nxt.p;
     const int stoff = st * (2 * HT_BYTES);
+    if constexpr (OP) {
+      const int pp = L0 + toff[t] + cur.t;
+      const int bo = H_ABYTES + pst * G::PATCH + (pp << 7) + ((fq ^ (pp & 7)) << 4);
+#pragma unroll
+      for (int jj = 0; jj < NP; ++jj) issueP(J0 + jj, pst ^ 1, sp);
+      issueHalf(st ^ 1, sa1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const char *bb = lds + (bo ^ (s << 6));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b0[j][s] = *(const frag_t *)(bb + j * 2048);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i][s] = *(const frag_t *)(ard[s] + stoff + i * 2048);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b1[j][s] = *(const frag_t *)(bb + H_BROW + j * 2048);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = mma(a[i][s], b0[j][s], acc[i][j]);
+            acc[i][2 + j] = mma(a[i][s], b1[j][s], acc[i][2 + j]);
+          }
+        // this A register quad is free: the A1 half tile's fragment takes its place, used 24+ MFMAs from now
+#pragma unroll
+        for (int s = 0; s < 2; ++s) a[i][s] = *(const frag_t *)(ard[s] + stoff + HT_BYTES + i * 2048);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[4 + i][j] = mma(a[i][s], b0[j][s], acc[4 + i][j]);
+            acc[4 + i][2 + j] = mma(a[i][s], b1[j][s], acc[4 + i][2 + j]);
+          }
+      // pin the interleave: (8 MFMAs, 2 LDS reads) x 4, then 32 MFMAs
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      hwait<0>();
+      __builtin_amdgcn_s_barrier();
+    } else {
     {   // phase A: A0 x (B rows wc | 4 + wc)
       const int pp = L0 + toff[t] + cur.t;
       const int bo = H_ABYTES + pst * G::PATCH + (pp << 7) + ((fq ^ (pp & 7)) << 4);
@@ -294,6 +372,7 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
         for (int i = 0; i < 4; ++i) a[i][s] = *(const frag_t *)(ard[s] + stoff + HT_BYTES + i * 2048);
       issueA0(st, sa2);
       CFD_SYNC_MFMA(4 + NP, CFD_MFMA(4, 0, b0) CFD_MFMA(4, 2, b1))
+    }
     }
   };
 
@@ -1064,6 +1143,8 @@ int igemm256h_launch(const IgemmParams &pin, int ntile, unsigned xbytes, unsigne
   typedef HaloGeo<4, true> GeoS2;
   typedef HaloGeo3<4, true> Geo3S2;
   typedef HaloGeoC<4, true> GeoCS2;
+  // cfd_set_tuning(CFD_TUNE_ONEPHASE, 0 | 1): the 256-wide kernel's one-cluster-per-K-tile schedule (A/B switch)
+  const bool onephase = tuning(CFD_TUNE_ONEPHASE) == 1;
   if (coresident && ntile == 64) {
     if (s2) CFD_LAUNCH_H((igemm128c_kernel<4, true, 64>), GeoCS2);
     else if (p.ntaps == 9) CFD_LAUNCH_H((igemm128c_kernel<9, false, 64>), HaloGeoC<9>);
@@ -1072,6 +1153,10 @@ int igemm256h_launch(const IgemmParams &pin, int ntile, unsigned xbytes, unsigne
     if (s2) CFD_LAUNCH_H((igemm128c_kernel<4, true>), GeoCS2);
     else if (p.ntaps == 9) CFD_LAUNCH_H(igemm128c_kernel<9>, HaloGeoC<9>);
     else CFD_LAUNCH_H(igemm128c_kernel<4>, HaloGeoC<4>);
+  } else if (ntile == 256 && onephase) {
+    if (s2) CFD_LAUNCH_H((igemm256h_kernel<4, true, true>), GeoS2);
+    else if (p.ntaps == 9) CFD_LAUNCH_H((igemm256h_kernel<9, false, true>), HaloGeo<9>);
+    else CFD_LAUNCH_H((igemm256h_kernel<4, false, true>), HaloGeo<4>);
   } else if (ntile == 256) {
     if (s2) CFD_LAUNCH_H((igemm256h_kernel<4, true>), GeoS2);
     else if (p.ntaps == 9) CFD_LAUNCH_H(igemm256h_kernel<9>, HaloGeo<9>);

@@ -55,10 +55,12 @@ const char *cfd_last_error(void);
  *                         co-resident form for 128-wide layers of at most 16 K tiles (per-tile overhead dominates there)
  *   CFD_TUNE_RESAMPLE_FUSED  -1 / 1: everything before the resample's search runs as ONE launch, a block per case (cases of up to
  *                         32 Ki points on average) | 0: the separate init / points / set-up / counting-sort launches
+ *   CFD_TUNE_ONEPHASE     1: the 256-wide patch-staged kernel runs ONE cluster of 64 MFMAs per K tile (A1 fragments re-read
+ *                         inside the cluster, LDS-DMA duty split by wave group) | 0 / -1: two clusters of 32 (igemm256h.hip)
  */
 typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_WGRAD256 = 2, CFD_TUNE_CLASS_ORDER = 3,
                CFD_TUNE_STAGED_OUT = 4, CFD_TUNE_RESAMPLE_DENSITY = 5, CFD_TUNE_NTILE = 6, CFD_TUNE_PATCH = 7,
-               CFD_TUNE_RESAMPLE_FUSED = 8, CFD_TUNE_COUNT = 9 } cfd_tuning_key;
+               CFD_TUNE_RESAMPLE_FUSED = 8, CFD_TUNE_ONEPHASE = 9, CFD_TUNE_COUNT = 10 } cfd_tuning_key;
 int cfd_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------

@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--ntile", type=int, default=-1, help="-1 heuristic, 128 / 256: n tile of the ping-pong kernels")
     ap.add_argument("--only", default="", help="comma list of layer names, e.g. e2,d4")
     ap.add_argument("--bias", type=int, default=0, help="1: forward launches add a bias vector (as the nets do)")
+    ap.add_argument("--onephase", default="", help="comma list of CFD_TUNE_ONEPHASE values timed side by side (e.g. 0,1)")
     ap.add_argument("--patch", default="-1", help="comma list of CFD_TUNE_PATCH values timed side by side per layer "
                                                    "(-1/1 patch kernels, 0 off, 2 co-resident for 128-wide, 3 co-resident everywhere)")
     args = ap.parse_args()
@@ -114,9 +115,14 @@ def main():
                    "dgrad": lambda: ops.conv_forward(dy, wtt, None, bk, cin, out=dx),
                    "wgrad": lambda: ops.conv_wgrad(x, dy, kind, cout, dw)}
             patches = [int(v) for v in args.patch.split(",")]
+            if args.onephase:                       # A/B of the one-cluster schedule instead of the patch modes
+                patches = [1000 + int(v) for v in args.onephase.split(",")]
             for m in modes:
                 for pm in patches:
-                    ops.set_tuning(ops.TUNE_PATCH, pm)
+                    if pm >= 1000:
+                        ops.set_tuning(ops.TUNE_ONEPHASE, pm - 1000)
+                    else:
+                        ops.set_tuning(ops.TUNE_PATCH, pm)
                     us = timeit(fns[m], args.iters)
                     tf = flops / us / 1e6
                     if pm == patches[0]:
@@ -125,6 +131,7 @@ def main():
                     print(f"{net:6s} {name:4s} {m:5s} B={B} in=({h},{w},{cin}) cout={cout} GFLOP={flops/1e9:8.2f} "
                           f"{us:9.1f} us {tf:8.1f} TF {tf/PEAK[args.dtype]:.3f}{tag}", flush=True)
             ops.set_tuning(ops.TUNE_PATCH, -1)
+            ops.set_tuning(ops.TUNE_ONEPHASE, -1)
     for m in modes:
         if tot[m][1] > 0:
             tf = tot[m][0] / tot[m][1] / 1e6

@@ -200,15 +200,27 @@ def test_conv_forward_igemm256_persistent(kind, B, H, W, cin, cout, split_k, pd)
     ("k4s2", 1, 32, 128, 192, 256),     # three chunks per group, 2 x 2 tiles: every image border in its own tile
     ("k4s2", 3, 16, 192, 128, 384),     # three tiles per row, three 128-wide n tiles
 ])
-@pytest.mark.parametrize("ntile", [256, 128])
+@pytest.mark.parametrize("ntile", [256, 128, 1256])      # 1256: the 256-wide kernel's one-cluster-per-K-tile schedule
 def test_conv_forward_patch_staged(kind, B, H, W, cin, cout, ntile):
     """igemm256h_kernel (activation operand staged once per channel chunk as an input patch; bf16 3x3 and transposed 4x4
     and, as four input-parity groups, 4x4 stride 2, on whole 8 x 32 tiles) against the oracle, against the per-tap kernel,
     and reading a channel slice of a wider input"""
     from cfd_amd import ops
     dtype, dev = torch.bfloat16, "cuda"
+    onephase = ntile > 1000
+    ntile = ntile % 1000
     if cout % ntile:
         pytest.skip("Cout is no multiple of this n tile")
+    ops.set_tuning(ops.TUNE_ONEPHASE, 1 if onephase else 0)
+    try:
+        _patch_staged_case(kind, B, H, W, cin, cout, ntile)
+    finally:
+        ops.set_tuning(ops.TUNE_ONEPHASE, -1)
+
+
+def _patch_staged_case(kind, B, H, W, cin, cout, ntile):
+    from cfd_amd import ops
+    dtype, dev = torch.bfloat16, "cuda"
     ops.set_tuning(ops.TUNE_NTILE, ntile)            # igemm256h_kernel / igemm128nh_kernel
     ops.set_tuning(ops.TUNE_PATCH, 1)                # (1: never the co-resident form, which has its own test below)
     try:
