@@ -259,12 +259,14 @@ def _cpu_baseline_train(seconds_budget):
 
 
 def csrc_sha16():
-    """sha256 (first 16 hex digits) over the kernel sources + this file: identifies the tree a profile was taken on
-    (the GPU box has no .git; scripts/collect_profiles.sh stamps the same digest into every profile it collects)"""
+    """sha256 (first 16 hex digits) over the kernel sources and the host modules that choose and launch them
+    (cfd_amd/csrc/*, cfd_amd/*.py): identifies the code a profile was taken on (the GPU box has no .git;
+    scripts/collect_profiles.sh stamps the same digest into every profile it collects).  bench.py itself is left out:
+    the workloads are named in the profile's own bench line, and an edit to the reporting code changes no kernel."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "cfd_amd", "csrc", "*"))) + [os.path.join(ROOT, "bench.py")]:
+    for f in sorted(glob.glob(os.path.join(ROOT, "cfd_amd", "csrc", "*"))) + sorted(glob.glob(os.path.join(ROOT, "cfd_amd", "*.py"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -318,7 +320,7 @@ def pmc_traffic_resample():
         ks = summary["kernels"]
         calls = ks["nearest_kernel"]["launches"]
         tot = sum(k["launches"] * (k.get("hbm_read_bytes_per_launch", 0) + k.get("hbm_write_bytes_per_launch", 0))
-                  for k in ks.values())
+                  for n, k in ks.items() if n != "nearest_kernel_counted")
         return round(tot / calls), profile_source(fs[-1], summary)
     except Exception:
         return None, None

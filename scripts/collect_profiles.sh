@@ -11,7 +11,7 @@ tag=$1; shift
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
-# identity of the tree these passes run on (the box has no .git): digest of the kernel sources + bench.py, compared by
+# identity of the tree these passes run on (the box has no .git): digest of the kernel sources + host modules, compared by
 # bench.py with the running tree when it quotes these counters (roofline.traffic_source.same_sources_as_this_run)
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench, json; json.dump({'csrc_sha16': bench.csrc_sha16(), 'git_head': '${CFD_GIT_HEAD:-}'}, open('$O/source_stamp.json', 'w'))" || exit 1
 cd /tmp && export TMPDIR=/tmp

@@ -29,11 +29,13 @@ os.makedirs(dst, exist_ok=True)
 
 def short(name):
     name = name.replace("void ", "")
-    for k in ("igemm256h_kernel", "igemm128nh_kernel"):      # patch-staged kernels: bf16 only, templated on the tap count
+    if "nearest_kernel<true>" in name:                        # the evaluation-counting variant: one call per bench run, not the timed path
+        return "nearest_kernel_counted"
+    for k in ("igemm256h_kernel", "igemm128nh_kernel", "igemm128c_kernel"):      # patch-staged kernels: bf16 only, templated on the tap count
         if k in name:
             return k + "<bf16>"
     for k in ("igemm256_kernel", "igemm128n_kernel", "igemm_kernel", "wgrad256_kernel", "wgrad_slab_reduce_kernel",
-              "conv_first_wgrad_kernel", "wgrad_kernel", "bn_apply_kernel", "bn_act_bwd_split_kernel", "bn_act_bwd_kernel", "bn_act_kernel",
+              "conv_first_wgrad_kernel", "wgrad_kernel", "bn_apply_kernel", "bn_act_bwd_split_kernel", "bn_act_bwd_kernel", "bn_act_kernel", "maxpool2_act_bwd_kernel", "act_bwd_kernel", "case_prepare_kernel",
               "conv_first_kernel", "adam_kernel", "splitk_epilogue_kernel", "tapgemm",
               "tap_dw_kernel", "tap_dx_kernel", "transpose_weight_kernel", "maxpool2", "nearest_kernel", "points_pass_kernel",
               "case_setup_kernel", "bin_count_kernel", "bin_scan_kernel", "bin_scatter_kernel", "resample_init_kernel",

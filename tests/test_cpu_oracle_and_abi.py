@@ -259,6 +259,6 @@ def test_ckdtree_choice_between_equidistant_points_depends_on_the_tree_not_on_th
         picks[leaf] = idx.tolist()
     assert picks[1] != picks[16], picks                         # same points, same queries, another answer
     # our rule on the same data: the lowest index, whatever the search structure
-    table = np.zeros((len(pts), 5))
-    table[:, 1:3] = pts
-    assert OR.nearest_index(table[:, 1:3], np.asarray(queries)).tolist() == [0] * len(queries)
+    # (a 2 x 2 pixel grid: its anti-diagonal pixels (0.5, 1.5) and (1.5, 0.5) are the ties)
+    got = OR.nearest_index(pts[:, 0], pts[:, 1], np.array([0.5, 1.5]), np.array([1.5, 0.5]))
+    assert got.tolist() == [0, 0, 1, 0]
