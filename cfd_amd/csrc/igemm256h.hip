@@ -106,6 +106,10 @@ template <int N> __device__ __forceinline__ void hwait() {
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
@@ -142,6 +146,12 @@ __device__ __forceinline__ HaloChunk halo_chunk(int g, int c, int cin2, int wi, 
 // for its own loads (vmcnt(0)) AFTER its cluster, before the closing barrier: the loads have a pre-cluster part and a whole
 // cluster (~1 500 cycles) to land.  Barrier intervals double (1 024 MFMA cycles against the ~190 cycles of hand-over that
 // kept the two-phase loop at 0.70-0.73 MFMA-busy).
+// CFD_DIAG (build-time, scripts/diag_variants.sh; never set in the shipped library): what bounds the K loop, found by
+// taking pieces of it away -- results are garbage, only the time means anything.  1: no LDS-DMA loads inside the K loop;
+// 2: no fragment reads after the first K tile; 4: no MFMAs; 8: no barriers inside the K loop.
+#ifndef CFD_DIAG
+#define CFD_DIAG 0
+#endif
 template <int NT, bool S2 = false, bool OP = false>
 __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -210,6 +220,16 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
     }
   }
 
+  if constexpr ((CFD_DIAG & 16) != 0) {   // every load out of range: zeros reach LDS, nothing is fetched
+#pragma unroll
+    for (int r = 0; r < 4; ++r) avoff[r] = OOB;
+#pragma unroll
+    for (int j = 0; j < G::PPW; ++j) pvoff[j] = OOB;
+  }
+  if constexpr ((CFD_DIAG & 32) != 0) {   // every weight load re-reads K tile 0 (L1 / L2 hits), the patch loads chunk 0
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wto[t] = 0;
+  }
   char *const ldsw = lds + wave * 1024;
   auto issueA0 = [&](int st, unsigned sa) {
     char *dst = ldsw + st * (2 * HT_BYTES);
@@ -272,16 +292,23 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
           _Pragma("unroll") for (int j = 0; j < 2; ++j)                                \
             acc[AI + i][BJ + j] = mma(a[i][s], BREG[j][s], acc[AI + i][BJ + j]);
+#define CFD_KBARRIER() do { if constexpr (!(CFD_DIAG & 8)) __builtin_amdgcn_s_barrier(); } while (0)
 #define CFD_SYNC_MFMA(VM, MFMAS)                                                       \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
-      hwait<VM>();                                                                     \
-      __builtin_amdgcn_s_barrier();                                                    \
+      hwait<(VM) + ((CFD_DIAG & 64) ? 2 : 0) + ((CFD_DIAG & 128) ? 4 : 0)>();            \
+      CFD_KBARRIER();                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                               \
       __builtin_amdgcn_s_setprio(1);                                                   \
-      MFMAS                                                                            \
+      if constexpr (!(CFD_DIAG & 4)) { MFMAS }                                         \
+      else {                                                                           \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(a[i][s]));   \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j) { asm volatile("" :: "v"(b0[j][s])); asm volatile("" :: "v"(b1[j][s])); } \
+        }                                                                              \
+      }                                                                                \
       __builtin_amdgcn_s_setprio(0);                                                   \
       __builtin_amdgcn_sched_barrier(0);                                               \
-      __builtin_amdgcn_s_barrier();
+      CFD_KBARRIER();
 
   auto ktile = [&](auto tc, int c) {
     constexpr int t = decltype(tc)::value;
@@ -347,9 +374,11 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
       hwait<0>();
       __builtin_amdgcn_s_barrier();
     } else {
+    const bool rd = !(CFD_DIAG & 2) || (c == 0 && t == 0);
     {   // phase A: A0 x (B rows wc | 4 + wc)
       const int pp = L0 + toff[t] + cur.t;
       const int bo = H_ABYTES + pst * G::PATCH + (pp << 7) + ((fq ^ (pp & 7)) << 4);
+      if (rd)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const char *bb = lds + (bo ^ (s << 6));
@@ -360,17 +389,20 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) b1[j][s] = *(const frag_t *)(bb + H_BROW + j * 2048);
       }
+      if constexpr (!(CFD_DIAG & 1)) {
 #pragma unroll
-      for (int jj = 0; jj < NP; ++jj) issueP(J0 + jj, pst ^ 1, sp);
-      issueA1(st ^ 1, sa1);
+        for (int jj = 0; jj < NP; ++jj) issueP(J0 + jj, pst ^ 1, sp);
+        issueA1(st ^ 1, sa1);
+      }
       CFD_SYNC_MFMA(4 + NP, CFD_MFMA(0, 0, b0) CFD_MFMA(0, 2, b1))
     }
     {   // phase B: A1 x (the same B fragments)
+      if (rd)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i][s] = *(const frag_t *)(ard[s] + stoff + HT_BYTES + i * 2048);
-      issueA0(st, sa2);
+      if constexpr (!(CFD_DIAG & 1)) issueA0(st, sa2);
       CFD_SYNC_MFMA(4 + NP, CFD_MFMA(4, 0, b0) CFD_MFMA(4, 2, b1))
     }
     }
@@ -386,6 +418,7 @@ __global__ __launch_bounds__(512, 2) void igemm256h_kernel(IgemmHaloParams P) {
     nxt = halo_chunk<S2>(ng, nc, cin2, p.Wi, ldx2);
   }
 #undef CFD_SYNC_MFMA
+#undef CFD_KBARRIER
 #undef CFD_MFMA
   if (wr == 0) __builtin_amdgcn_s_barrier();
   hwait<0>();   // the tail loads must not outlive the workgroup's LDS allocation
