@@ -391,10 +391,21 @@ def run_model_workload(name, B, steps, warmup, rank, world, cpu_base):
         kt = ops.KernelTimer(sync=False)   # (creates its events here, ahead of the delay)
         torch.cuda.synchronize()
         torch.cuda._sleep(head_start)
-        step_fn(999)                       # not counted: runs while the host queues the counted steps
-        with kt:
-            for s in range(n_roof):
-                step_fn(1000 + s)
+        # (the training steps put their weight-gradient GEMMs on a second stream by default; brackets on two streams
+        # overlap and would count the shared time twice, so THIS pass runs them on the launch stream: the roofline is of
+        # the kernels, `ms_per_step` above is of the step as shipped)
+        wstream = os.environ.get("CFD_AMD_WGRAD_STREAM")
+        os.environ["CFD_AMD_WGRAD_STREAM"] = "0"
+        try:
+            step_fn(999)                   # not counted: runs while the host queues the counted steps
+            with kt:
+                for s in range(n_roof):
+                    step_fn(1000 + s)
+        finally:
+            if wstream is None:
+                del os.environ["CFD_AMD_WGRAD_STREAM"]
+            else:
+                os.environ["CFD_AMD_WGRAD_STREAM"] = wstream
         sm = kt.summary()
         achieved = sm["total_flops"] / (sm["total_ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[wl["dtype"]]

@@ -75,7 +75,7 @@ class _Net:
     def wgrad_begin(self, side: bool) -> None:
         self._wg_side = bool(side)
         if side and getattr(self, "_wg_stream", None) is None:
-            self._wg_stream = torch.cuda.Stream(device=self.device)
+            self._wg_stream = ops.side_stream("wgrad")
 
     def wgrad(self, fn) -> None:
         """run `fn` (weight-gradient launches) behind everything enqueued so far, on the side stream if enabled"""

@@ -83,6 +83,21 @@ _ws_cache = {}
 _ws_lane = 0          # which scratch `_workspace` hands out: 0 = the launch stream's, 1 = the weight-gradient side stream's
 
 
+_side_streams: dict = {}
+
+
+def side_stream(name: str) -> "torch.cuda.Stream":
+    """ONE stream per purpose and process ('wgrad', 'transpose'), shared by every net and parameter store.  The box gives a
+    process four hardware queues (GPU_MAX_HW_QUEUES); with a stream per object the U training step had five (compute,
+    a weight-gradient stream per net, a transpose stream per parameter store), two of them folded onto one queue, and
+    WHICH two differed from process to process: the same step ran 7.54 ms or 9.4 ms (round 3, three processes in a row on
+    one box).  Work on streams of one purpose never overlaps in time anyway (G's and D's backward alternate)."""
+    st = _side_streams.get(name)
+    if st is None:
+        st = _side_streams[name] = torch.cuda.Stream()
+    return st
+
+
 class KernelTimer:
     """Brackets every cfd_conv_forward launch with HIP events on the launch stream (torch's current
     stream IS the stream the kernels are launched on) and records their algorithmic FLOPs.

@@ -124,7 +124,7 @@ class ParamStore:
             return
         if side_stream and self.master.is_cuda:
             if self._t_stream is None:
-                self._t_stream = torch.cuda.Stream()
+                self._t_stream = ops.side_stream("transpose")
             self.wait_transposed()                     # never two refreshes in flight
             ev = torch.cuda.Event()
             ev.record()

@@ -383,11 +383,15 @@ class BackwardBuckets:
 def _side_wgrad(dp) -> bool:
     """weight-gradient GEMMs on a second stream beside the data-gradient chain (nets._Net.wgrad): single-GPU steps only
     -- under data parallelism `ready(layer)` hands gradient ranges to RCCL as the backward produces them, which needs
-    them complete on the launching stream.  Opt-in (CFD_AMD_WGRAD_STREAM=1): measured 8.65 -> 8.49 ms per B=16 step on
-    one box (-1.9 %), i.e. inside the box-to-box spread, while every GEMM's own duration grows under the sharing (the
-    per-kernel roofline brackets overlap), so the default keeps one stream."""
+    them complete on the launching stream.  On by default since round 3 (CFD_AMD_WGRAD_STREAM=0 turns it off): the
+    B = 16 U step 7.92 -> 7.77 ms (-1.9 %, three interleaved pairs on one box; the same -1.9 % round 2 measured).  The
+    small-M layers' GEMMs leave most CUs idle for part of their run; a second GEMM fills them.  Every GEMM's OWN
+    duration grows under the sharing, so bench.py's per-launch roofline brackets are taken with the switch off (the
+    brackets of two streams overlap and would count the shared time twice); the step time is measured with it on.
+    The side streams are process-wide (ops.side_stream): with one per net the step had more streams than hardware queues
+    and a slow mode (9.4 ms) that came and went with the queue assignment."""
     import os
-    return dp.world == 1 and os.environ.get("CFD_AMD_WGRAD_STREAM", "0") == "1"
+    return dp.world == 1 and os.environ.get("CFD_AMD_WGRAD_STREAM", "1") != "0"
 
 
 class DiscriminatorTrainer:
