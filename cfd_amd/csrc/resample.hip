@@ -27,7 +27,7 @@
 //                      every z slice it is near (replaces 101 scans of the table per case)
 //   case_setup         per case: decode the slices, np.interp the wall to the W columns, choose the cell grid
 //   bin_count / bin_scan / bin_scatter   counting sort of the points by cell (cell lists)
-//   nearest_kernel     8 x 32-pixel tiles; ring search; the tile's 5-column rows leave through LDS as
+//   nearest_kernel     16 x 32-pixel tiles (two pixels per lane); ring search; the tile's 5-column rows leave through LDS as
 //                      contiguous runs (whole 128-B lines), not as five 8-B stores at 40-B lane stride
 #include "common.h"
 
@@ -597,8 +597,9 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int TILE_H = 8, TILE_W = 32;   // pixels per block: 8 rows x 32 columns; one wave = 8 rows x 8 columns
-constexpr int WIN_CAP = 128;             // points a wave stages in LDS for its 64 pixels
+constexpr int NPX = 2;                   // pixels per lane: rows lr and lr + 8 of the wave's 16 x 8 pixels
+constexpr int TILE_H = 8 * NPX, TILE_W = 32;   // pixels per block: 16 rows x 32 columns; one wave = 16 rows x 8 columns
+constexpr int WIN_CAP = 128;             // points a wave stages in LDS for its pixels
 constexpr int WIN_ROWS = 8;              // cell rows of a wave's window at most (else the general search)
 
 // General search of one pixel: rings of cells around its own cell, read from global memory, with the exact stop test
@@ -659,8 +660,15 @@ __device__ void ring_search(double qy, double qz, const CaseGrid &G, const int *
 // values) plus ~35 FP64 distance evaluations per pixel; (p, U) ride with the window so the last round trip is LDS.
 // COUNT: also tally the distance evaluations (one = two subtractions, two products, one sum, in fp64) into *evals -- the
 // bench's FP64 roofline of this kernel is measured work, not an estimate (cfd_resample_nearest_counted)
+// Occupancy: 18 KiB of LDS per block = 8 blocks = 32 waves per CU; left to itself the compiler takes 80+ registers (6 waves
+// per SIMD), held to 8 waves it needs 63 and spills nothing (the counting variant spills; it runs once per bench) -- the
+// kernel is a latency chain, so the two extra waves pay: 257 -> 251 us per 256-case call.
+// Two pixels per lane (rows lr and lr + 8: a wave owns 16 x 8 pixels, round 3): a wave's chain of dependent round trips
+// (case record -> cell starts -> points) is paid once per 128 pixels instead of once per 64, every window point read from
+// LDS serves two pixels and the column term (z - qz)^2 is shared; the window grows by one or two cell rows, so the
+// evaluations per pixel go 23.8 -> 31.7 -- and the call 251 -> 226 us.  Four pixels per lane: 41.7 evaluations, 234 us.
 template <bool COUNT>
-__global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict__ offs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void nearest_kernel(const int64_t *__restrict__ offs,
                                                      int ncase, const double *__restrict__ yf, int H,
                                                      const double *__restrict__ zf, int W, int S,
                                                      const double *__restrict__ wall, int64_t wall_stride,
@@ -694,15 +702,24 @@ __global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict_
   }
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int lr = lane >> 3, lc = wave * 8 + (lane & 7);          // row / column inside the block's tile
-  const int i = ty * TILE_H + lr, j = tx * TILE_W + lc;
-  const bool live = i < H && j < W;
+  const int lr = lane >> 3, lc = wave * 8 + (lane & 7);          // row (of the first pixel) / column inside the block's tile
+  const int j = tx * TILE_W + lc;
   // everything that depends on nothing but the block's coordinates is requested first, in one round trip
   const int64_t beg = offs[cs];
   const CaseGrid G = load_grid(grid, cs);
-  const double qy = yf[live ? i : 0], qz = zf[live ? j : 0];
   const double *w = wall + (int64_t)cs * wall_stride;
-  const double ylo = w[2 * S + (live ? j : 0)], yhi = w[2 * S + W + (live ? j : 0)];
+  const bool livec = j < W;
+  const double qz = zf[livec ? j : 0];
+  const double ylo = w[2 * S + (livec ? j : 0)], yhi = w[2 * S + W + (livec ? j : 0)];
+  double qy[NPX];
+  bool wanted[NPX];
+#pragma unroll
+  for (int h = 0; h < NPX; ++h) {
+    const int i = ty * TILE_H + h * 8 + lr;
+    const bool live = livec && i < H;
+    qy[h] = yf[live ? i : 0];
+    wanted[h] = live && !(qy[h] < ylo || qy[h] > yhi);   // (comparisons with NaN are false, as in numpy: then search)
+  }
   const int *st = start + cell_base(cs, beg) + cs;
   const double2 *sp = syz + beg;
   const double2 *su = spu + beg;
@@ -710,12 +727,16 @@ __global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict_
   double2 *wpts = (double2 *)lds + wave * 2 * WIN_CAP;
   double2 *wpu = wpts + WIN_CAP;
   int *wid = wids[wave];
-  const bool wanted = live && !(qy < ylo || qy > yhi);   // (comparisons with NaN are false, as in numpy: then search)
 
   // ---- the wave's window of cells (over the pixels that need a nearest point)
-  int cqy = 0, cqz = 0;
-  if (wanted) { cqy = bin1(qy, G.y0, G.invy, G.hy, G.ny); cqz = bin1(qz, G.z0, G.invz, G.hz, G.nz); }
-  int ymin = wanted ? cqy : 0x7fffffff, ymax = wanted ? cqy : -1, zmin = wanted ? cqz : 0x7fffffff, zmax = wanted ? cqz : -1;
+  int ymin = 0x7fffffff, ymax = -1, zmin = 0x7fffffff, zmax = -1;
+#pragma unroll
+  for (int h = 0; h < NPX; ++h)
+    if (wanted[h]) {
+      const int cqy = bin1(qy[h], G.y0, G.invy, G.hy, G.ny), cqz = bin1(qz, G.z0, G.invz, G.hz, G.nz);
+      ymin = cqy < ymin ? cqy : ymin; ymax = cqy > ymax ? cqy : ymax;
+      zmin = cqz < zmin ? cqz : zmin; zmax = cqz > zmax ? cqz : zmax;
+    }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const int a = __shfl_xor(ymin, o), b = __shfl_xor(ymax, o), c = __shfl_xor(zmin, o), d = __shfl_xor(zmax, o);
@@ -762,62 +783,80 @@ __global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict_
   }
   wave_sync();                                       // the wave's LDS writes before its reads
 
-  double P = 0.0, U = 0.0;
-  if (wanted) {
-    double best = dinf();
-    bool decided = false;
-    if (fast) {
-      // first pass: strict minimum in scan order, and whether any candidate EQUALLED the running minimum -- only
-      // then (rare) the pass is repeated with the lowest-original-index tie rule
-      int bk = -1;
-      bool tie = false;
-      int k = 0;
-      for (; k + 4 <= T; k += 4) {
-        const double2 s0 = wpts[k], s1 = wpts[k + 1], s2 = wpts[k + 2], s3 = wpts[k + 3];
-        const double y0 = s0.x - qy, z0 = s0.y - qz, y1 = s1.x - qy, z1 = s1.y - qz;
-        const double y2 = s2.x - qy, z2 = s2.y - qz, y3 = s3.x - qy, z3 = s3.y - qz;
-        const double d0 = y0 * y0 + z0 * z0, d1 = y1 * y1 + z1 * z1;   // two products, one sum, each rounded
-        const double d2 = y2 * y2 + z2 * z2, d3 = y3 * y3 + z3 * z3;   // (contraction is off)
-        tie |= d0 == best; if (d0 < best) { best = d0; bk = k; }
-        tie |= d1 == best; if (d1 < best) { best = d1; bk = k + 1; }
-        tie |= d2 == best; if (d2 < best) { best = d2; bk = k + 2; }
-        tie |= d3 == best; if (d3 < best) { best = d3; bk = k + 3; }
+  double P[NPX], U[NPX];
+#pragma unroll
+  for (int h = 0; h < NPX; ++h) { P[h] = 0.0; U[h] = 0.0; }
+  bool decided[NPX];
+#pragma unroll
+  for (int h = 0; h < NPX; ++h) decided[h] = !wanted[h];
+  if (fast && (wanted[0] || wanted[NPX - 1])) {
+    // first pass, both pixels of the lane against every point read: strict minimum in scan order, and whether any candidate
+    // EQUALLED the running minimum -- only then (rare) that pixel's pass is repeated with the lowest-original-index tie rule
+    double best[NPX];
+    int bk[NPX];
+    bool tie[NPX];
+#pragma unroll
+    for (int h = 0; h < NPX; ++h) { best[h] = dinf(); bk[h] = -1; tie[h] = false; }
+    int k = 0;
+    for (; k + 2 <= T; k += 2) {
+      const double2 s0 = wpts[k], s1 = wpts[k + 1];
+      const double z0 = s0.y - qz, z1 = s1.y - qz;
+      const double zz0 = z0 * z0, zz1 = z1 * z1;      // (the column term is shared by the lane's pixels: same rounding)
+#pragma unroll
+      for (int h = 0; h < NPX; ++h) {
+        const double y0 = s0.x - qy[h], y1 = s1.x - qy[h];
+        const double d0 = y0 * y0 + zz0, d1 = y1 * y1 + zz1;   // two products, one sum, each rounded (contraction is off)
+        tie[h] |= d0 == best[h]; if (d0 < best[h]) { best[h] = d0; bk[h] = k; }
+        tie[h] |= d1 == best[h]; if (d1 < best[h]) { best[h] = d1; bk[h] = k + 1; }
       }
-      for (; k < T; ++k) {
-        const double2 s = wpts[k];
-        const double dy = s.x - qy, dz = s.y - qz;
-        const double d = dy * dy + dz * dz;
-        tie |= d == best; if (d < best) { best = d; bk = k; }
+    }
+    for (; k < T; ++k) {
+      const double2 s = wpts[k];
+      const double dz = s.y - qz;
+      const double zz = dz * dz;
+#pragma unroll
+      for (int h = 0; h < NPX; ++h) {
+        const double dy = s.x - qy[h];
+        const double d = dy * dy + zz;
+        tie[h] |= d == best[h]; if (d < best[h]) { best[h] = d; bk[h] = k; }
       }
+    }
+#pragma unroll
+    for (int h = 0; h < NPX; ++h) {
+      if (!wanted[h]) continue;
       nev += (unsigned)T;
-      if (tie) {
+      if (tie[h]) {
         nev += (unsigned)T;
-        best = dinf(); bk = -1;
+        best[h] = dinf(); bk[h] = -1;
         for (k = 0; k < T; ++k) {
           const double2 s = wpts[k];
-          const double dy = s.x - qy, dz = s.y - qz;
+          const double dy = s.x - qy[h], dz = s.y - qz;
           const double d = dy * dy + dz * dz;
-          if (d < best) { best = d; bk = k; }
-          else if (d == best && bk >= 0 && wid[k] < wid[bk]) bk = k;   // ties: the lowest original index
+          if (d < best[h]) { best[h] = d; bk[h] = k; }
+          else if (d == best[h] && bk[h] >= 0 && wid[k] < wid[bk[h]]) bk[h] = k;   // ties: the lowest original index
         }
       }
-      if (wy0 == 0 && wy1 == G.ny - 1 && wz0 == 0 && wz1 == G.nz - 1) decided = true;   // the window is the whole grid
+      if (wy0 == 0 && wy1 == G.ny - 1 && wz0 == 0 && wz1 == G.nz - 1) decided[h] = true;   // the window is the whole grid
       else {
         double B = dinf();
-        if (wy1 < G.ny - 1) { const double t = G.by(wy1 + 1) - qy; B = fmin(B, t * t); }
-        if (wy0 > 0)        { const double t = G.by(wy0) - qy;     B = fmin(B, t * t); }
+        if (wy1 < G.ny - 1) { const double t = G.by(wy1 + 1) - qy[h]; B = fmin(B, t * t); }
+        if (wy0 > 0)        { const double t = G.by(wy0) - qy[h];     B = fmin(B, t * t); }
         if (wz1 < G.nz - 1) { const double t = G.bz(wz1 + 1) - qz; B = fmin(B, t * t); }
         if (wz0 > 0)        { const double t = G.bz(wz0) - qz;     B = fmin(B, t * t); }
-        decided = best < B;
+        decided[h] = best[h] < B;
       }
-      if (decided && bk >= 0) { const double2 pu = wpu[bk]; P = pu.x; U = pu.y; }
+      if (decided[h] && bk[h] >= 0) { const double2 pu = wpu[bk[h]]; P[h] = pu.x; U[h] = pu.y; }
     }
-    if (!decided) {
+  }
+#pragma unroll
+  for (int h = 0; h < NPX; ++h) {
+    if (!decided[h]) {
+      double best;
       int bestk;
-      ring_search(qy, qz, G, st, sp, si, best, bestk, nev);
-      if (bestk >= 0) { const double2 pu = su[bestk]; P = pu.x; U = pu.y; }
+      ring_search(qy[h], qz, G, st, sp, si, best, bestk, nev);
+      if (bestk >= 0) { const double2 pu = su[bestk]; P[h] = pu.x; U[h] = pu.y; }
     }
-    if (P < 0.0) P = 0.0;                            // :182
+    if (P[h] < 0.0) P[h] = 0.0;                      // :182
   }
   if constexpr (COUNT) {
     unsigned t = nev;
@@ -825,20 +864,24 @@ __global__ __launch_bounds__(256) void nearest_kernel(const int64_t *__restrict_
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
     if (lane == 0 && t) atomicAdd(evals, (unsigned long long)t);
   }
-  wave_sync();                                       // every lane is done with the window: the output rows take its place
+  // a row of the wave's pixels = up to 8 pixels x 5 columns = 40 consecutive doubles of the output table; the wave's two
+  // groups of 8 rows leave one after the other through the window's LDS bytes
   double *stage = (double *)wpts;
-  double *s5 = stage + lane * 5;                     // lane = row lr (8) x column (8) of the wave's 8 x 8 pixels
-  s5[0] = qy; s5[1] = qz; s5[2] = P; s5[3] = U; s5[4] = P * p_convert;
-  wave_sync();
-  // a row of the wave's pixels = up to 8 pixels x 5 columns = 40 consecutive doubles of the output table
   const int col0 = tx * TILE_W + wave * 8;
   const int cols = (W - col0) < 8 ? (W - col0) : 8;  // (<= 0: the whole wave is outside the image)
 #pragma unroll
-  for (int e = lane; e < 64 * 5; e += 64) {
-    const int r = e / 40, k = e - r * 40;
-    const int row = ty * TILE_H + r;
-    if (row < H && k < cols * 5)
-      out[(((int64_t)cs * H + row) * W + col0) * 5 + k] = stage[e];
+  for (int h = 0; h < NPX; ++h) {
+    wave_sync();                                     // every lane is done with the window / the previous group's rows
+    double *s5 = stage + lane * 5;                   // lane = row lr (8) x column (8) of the group's 8 x 8 pixels
+    s5[0] = qy[h]; s5[1] = qz; s5[2] = P[h]; s5[3] = U[h]; s5[4] = P[h] * p_convert;
+    wave_sync();
+#pragma unroll
+    for (int e = lane; e < 64 * 5; e += 64) {
+      const int r = e / 40, k = e - r * 40;
+      const int row = ty * TILE_H + h * 8 + r;
+      if (row < H && k < cols * 5)
+        out[(((int64_t)cs * H + row) * W + col0) * 5 + k] = stage[e];
+    }
   }
 }
 
