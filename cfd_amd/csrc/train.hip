@@ -765,6 +765,130 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float *__re
   }
 }
 
+// The same gradient, lane = (pixel lane, group of CPL output channels) (round 3).  The kernel above spends one LDS read per
+// FMA (thread = one channel: a patch value serves one FMA) and loads the gradient rows 2 bytes per lane; DeltaP g1 at
+// B = 64 took 165 us for 268 MB of gradient rows (1.8 TB/s) with the vector ALU issuing two instructions per FMA.  Here a
+// lane keeps CPL channels x NW taps of accumulators (72 for g1's 3 x 3 taps x 8 channels), loads its CPL gradient values of eight
+// pixels with 16 / 8 / 4-byte accesses ahead of the patch staging (one pixel per thread: two divisions per staged pixel
+// instead of three per staged element) and does CPL FMAs per LDS read.
+template <typename T, int KS, int S, int CIN, int CPL>
+__global__ __launch_bounds__(256) void conv_first_wgrad2_kernel(const float *__restrict__ x, const float *__restrict__ x2,
+                                                               int cin1, const T *__restrict__ dpre, int ldd,
+                                                               float *__restrict__ dw, float *__restrict__ db, int B,
+                                                               int Hi, int Wi, int Ho, int Wo, int Cout, int lg_ncgp,
+                                                               int pix_per_block) {
+  constexpr int NW = KS * KS * CIN, NWP = NW | 1;    // odd row pitch: the staging writes and the reads spread over the banks
+  constexpr int PPT = 8;                             // pixels per thread and step
+  __shared__ float red[256 * CPL];
+  __shared__ float sh[256 * (NW + 1)];               // the step's patches [pixel][NWP]; after the loop the block's sums [co][NW]
+  const int tid = threadIdx.x;
+  const int ncgp = 1 << lg_ncgp, npl = 256 >> lg_ncgp;
+  const int cg = tid & (ncgp - 1), pl = tid >> lg_ncgp;
+  const int ncg = Cout / CPL;
+  const int c0 = (cg < ncg ? cg : 0) * CPL;          // (lanes beyond the channels load a valid address; never summed)
+  const int pixb = npl * PPT;                        // pixels per step (<= 256)
+  float acc[CPL][NW], accb[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    accb[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) acc[c][k] = 0.f;
+  }
+  const unsigned npix = (unsigned)B * Ho * Wo;
+  const unsigned p0 = blockIdx.x * (unsigned)pix_per_block;
+  const unsigned p1 = (p0 + pix_per_block < npix) ? p0 + pix_per_block : npix;
+  const int cin2 = CIN - cin1;
+  for (unsigned pb = p0; pb < p1; pb += pixb) {
+    // the step's gradient rows first: their latency runs under the patch staging
+    float gv[PPT][CPL];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const unsigned pix = pb + pl + npl * i;
+      const T *src = dpre + (size_t)(pix < p1 ? pix : p1 - 1) * ldd + c0;
+      const bool ok = pix < p1;
+      if constexpr (sizeof(T) == 2) {
+        if constexpr (CPL == 8) { const bf16x8 v = *(const bf16x8 *)src;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) gv[i][c] = ok ? (float)v[c] : 0.f; }
+        else if constexpr (CPL == 4) { const bf16x4 v = *(const bf16x4 *)src;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) gv[i][c] = ok ? (float)v[c] : 0.f; }
+        else { const bf16x2 v = *(const bf16x2 *)src; gv[i][0] = ok ? (float)v[0] : 0.f; gv[i][1] = ok ? (float)v[1] : 0.f; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CPL; c += 2) {
+          const f32x2 v = *(const f32x2 *)(src + c);
+          gv[i][c] = ok ? v[0] : 0.f; gv[i][c + 1] = ok ? v[1] : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < pixb) {                                // one pixel per thread
+      const unsigned pix = pb + tid;
+      float pv[NW];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) pv[k] = 0.f;
+      if (pix < p1) {
+        const unsigned row = pix / (unsigned)Wo;
+        const int ox = (int)(pix - row * Wo), b = (int)(row / (unsigned)Ho), oy = (int)(row - (unsigned)b * Ho);
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh) {
+          const int iy = oy * S - 1 + kh;
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            const int ix = ox * S - 1 + kw;
+            if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) {
+              const size_t ip = ((size_t)b * Hi + iy) * Wi + ix;
+#pragma unroll
+              for (int ci = 0; ci < CIN; ++ci)
+                pv[(kh * KS + kw) * CIN + ci] = ci < cin1 ? x[ip * cin1 + ci] : x2[ip * cin2 + (ci - cin1)];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NW; ++k) sh[tid * NWP + k] = pv[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float *pp = sh + (pl + npl * i) * NWP;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) accb[c] += gv[i][c];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        const float pvk = pp[k];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c][k] = fmaf(gv[i][c], pvk, acc[c][k]);
+      }
+    }
+  }
+  // ---- block reduction over the pixel lanes, one tap at a time through 8 KiB of LDS; the sums leave as one contiguous
+  // burst of atomics (dw is [co][tap][ci] = [co][k])
+  float *osum = sh;
+#pragma unroll
+  for (int k = 0; k <= NW; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) red[tid * CPL + c] = k < NW ? acc[c][k < NW ? k : 0] : accb[c];
+    __syncthreads();
+    float t[(256 + 255) / 256];
+    for (int co = tid, n = 0; co < Cout; co += 256, ++n) {
+      const int g = co / CPL, c = co - g * CPL;
+      float tt = 0.f;
+      for (int q = 0; q < npl; ++q) tt += red[((q << lg_ncgp) + g) * CPL + c];
+      t[n] = tt;
+    }
+    if (k == 0) __syncthreads();                    // (every thread is done reading the last step's patches before sh is reused)
+    for (int co = tid, n = 0; co < Cout; co += 256, ++n) {
+      if (k < NW) osum[co * NW + (k < NW ? k : 0)] = t[n];
+      else if (db) atomicAdd(db + co, t[n]);
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < Cout * NW; e += 256) atomicAdd(dw + e, osum[e]);
+}
+
 // Streaming kernels get ONE vector per thread (no cap): measured on the Adam update over 128 Mi parameters
 // (scripts/micro/adam_bw.hip), a grid-stride loop over 8 192 blocks runs at 4.0-4.1 TB/s, the uncapped grid at 5.4 -- with a
 // capped grid every block's next iteration lands 32 MB further on in eight streams at once.  Kernels that keep
@@ -1089,6 +1213,37 @@ extern "C" int cfd_conv_first_wgrad(const float *x, const float *x2, int cin1, i
   ppb = (ppb + 127) / 128 * 128;     // a multiple of every variant's step (32 pixels x 1, 2 or 4 groups)
   const int blocks = (int)((npix + ppb - 1) / ppb);
   const int cin = cin1 + cin2;
+  // lane = (pixel lane, group of CPL channels) when the channels divide into at most 64 groups (every first layer of the
+  // reference's graphs: g1 64, e1 256 / 128, c1 64 channels); else the thread-per-channel kernel below
+  {
+    const int nw = ksize * ksize * cin;
+    const int cpl = nw <= 9 ? 8 : (nw <= 16 ? 4 : 2);
+    int lg = 3;
+    while ((1 << lg) * cpl < Cout) ++lg;
+    const size_t es = dtype == CFD_BF16 ? 2 : 4;
+    const bool aligned = ((uintptr_t)dpre % (cpl * es)) == 0 && ((size_t)ldd * es) % (cpl * es) == 0;
+    const bool x2ok = (cin2 > 0) == (x2 != nullptr);
+    if (Cout % cpl == 0 && lg <= 6 && aligned && x2ok) {
+      const int step = (256 >> lg) * 8;            // pixels per staged step
+      int64_t ppb2 = (npix + 1023) / 1024;
+      ppb2 = (ppb2 + step - 1) / step * step;
+      const dim3 grid((unsigned)((npix + ppb2 - 1) / ppb2));
+#define CFW2(T, KS, S, CIN, CPL)                                                                                       \
+  hipLaunchKernelGGL((conv_first_wgrad2_kernel<T, KS, S, CIN, CPL>), grid, dim3(256), 0, st, x, x2, cin1, (const T *)dpre, \
+                     ldd, dw, db, B, Hi, Wi, Ho, Wo, Cout, lg, (int)ppb2)
+      // measured (interleaved A/B, one box): DeltaP's step 3.336 -> 3.269 ms with g1 here (3 x 3, 8 channels per lane); the
+      // 4 x 4 first layers (e1: 4 channels per lane, c1: 2) have 32 / 64-pixel steps here and ran the U step 0.7 % SLOWER
+      // than the thread-per-channel kernel, so they stay there
+      bool done = true;
+      if (ksize == 3 && stride == 1 && cin == 1) { if (dtype == CFD_BF16) CFW2(bf16, 3, 1, 1, 8); else CFW2(float, 3, 1, 1, 8); }
+      else done = false;
+#undef CFW2
+      if (done) {
+        CFD_LAUNCH_CHECK();
+        return CFD_OK;
+      }
+    }
+  }
 #define CFW_(T, KS, S, CIN, CG)                                                                                   \
   hipLaunchKernelGGL((conv_first_wgrad_kernel<T, KS, S, CIN, CG>), dim3(blocks), dim3(256), 0, st, x, x2, cin1,    \
                      (const T *)dpre, ldd, dw, db, B, Hi, Wi, Ho, Wo, Cout, (int)ppb)
