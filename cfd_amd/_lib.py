@@ -17,6 +17,7 @@ CONV_K4S2, CONV_K4S1, CONV_K3S1, CONVT_K4S2, DENSE, CONV_K4S1_BWD = 0, 1, 2, 3, 
 TUNE_IGEMM256, TUNE_IGEMM256_PD, TUNE_WGRAD256, TUNE_CLASS_ORDER, TUNE_STAGED_OUT, TUNE_RESAMPLE_DENSITY, TUNE_NTILE, TUNE_PATCH = 0, 1, 2, 3, 4, 5, 6, 7
 TUNE_RESAMPLE_FUSED = 8
 TUNE_ONEPHASE = 9
+TUNE_SKINNY = 10
 
 
 class ConvDesc(C.Structure):

@@ -24,7 +24,7 @@ char *last_error_buf() {
 }
 
 // tuning knobs (process-wide; -1 = built-in heuristic)
-static int g_tuning[CFD_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+static int g_tuning[CFD_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 int tuning(int key) { return (key >= 0 && key < CFD_TUNE_COUNT) ? g_tuning[key] : -1; }
 }  // namespace cfd
 

@@ -37,11 +37,18 @@ constexpr int TILE_BYTES = 128 * 128;      // one operand tile: 128 rows x 128 B
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;
 
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
+// MT = rows of the m tile: 128, or 32 for the layers with a handful of output pixels per class (round 3: at batch 1 -- the
+// reference's own batch size -- U's e5, b, d1, d2 have 8 or 32 pixels; on a 128-row tile their fp32 MFMAs ran 94 % on
+// padding and the weight-bound layers took 47-80 us for 67-134 MB of weights).  MT = 32: the four waves split the 128
+// n rows (32 x 32 wave tiles), a stage is 16 + 4 KiB, four workgroups share a CU and the host splits K further.
+template <typename T, int MT = 128>
+__global__ __launch_bounds__(256, MT == 128 ? 2 : 4) void igemm_kernel(IgemmParams p) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BKE = Elem<T>::BKE;
   constexpr int ES = sizeof(T);
+  constexpr int XR = MT / 32;                       // staging rounds of the activation tile (32 rows each)
+  constexpr int STAGE = TILE_BYTES + MT * 128;      // weights 128 x 128 B + activations MT x 128 B
+  constexpr int NI = MT == 128 ? 4 : 2, MJ = MT == 128 ? 4 : 2;   // 16 x 16 fragments per wave: n x m
   extern __shared__ __attribute__((aligned(1024))) char lds[];
 
   const int tid = threadIdx.x;
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
   const int cls = bid % p.nclass;
   const int sk = bid / p.nclass;
   const int ph = cls >> 1, pw = cls & 1;
-  const int m0 = mt * 128, n0 = nt * 128;
+  const int m0 = mt * MT, n0 = nt * 128;
 
   const int S = (p.kind == CFD_CONV_K4S2) ? 2 : 1;
 
@@ -72,14 +79,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int R = (i * 4 + wave) * 8 + lrow;
-    const int m = m0 + R;
-    mval[i] = m < p.M;
-    const int mm = mval[i] ? m : 0;
-    int b, qy, qx;
-    split_pixel(p, mm, b, qy, qx);
-    ybase[i] = qy * S;
-    xbase[i] = qx * S;
-    pix0[i] = (b * p.Hi + qy * S) * p.Wi + qx * S;
+    if (i < XR) {
+      const int m = m0 + R;
+      mval[i] = m < p.M;
+      const int mm = mval[i] ? m : 0;
+      int b, qy, qx;
+      split_pixel(p, mm, b, qy, qx);
+      ybase[i] = qy * S;
+      xbase[i] = qx * S;
+      pix0[i] = (b * p.Hi + qy * S) * p.Wi + qx * S;
+    }
     const int n = n0 + R;
     wrow[i] = (n < p.Cout) ? p.w + ((int64_t)n * p.Kw + chunk * EPC) * ES : nullptr;
   }
@@ -102,20 +111,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       wtap_row[i] = wrow[i] ? wrow[i] + woff : nullptr;
-      const int iy = ybase[i] + dy, ix = xbase[i] + dx;
-      const bool ok = mval[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      xrow[i] = ok ? p.x + ((int64_t)(pix0[i] + dy * p.Wi + dx) * p.ldx + chunk * EPC) * ES : nullptr;
+      if (i < XR) {
+        const int iy = ybase[i] + dy, ix = xbase[i] + dx;
+        const bool ok = mval[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        xrow[i] = ok ? p.x + ((int64_t)(pix0[i] + dy * p.Wi + dx) * p.ldx + chunk * EPC) * ES : nullptr;
+      }
     }
   };
   tap_setup();
   auto stage = [&](int /*kt*/, int buf) {
-    char *wdst = lds + buf * STAGE_BYTES + wave * 1024;
+    char *wdst = lds + buf * STAGE + wave * 1024;
     char *xdst = wdst + TILE_BYTES;
     const int cib = st_c * BKE * ES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       glds16(wtap_row[i] ? wtap_row[i] + cib : zero, wdst + i * 4096);
-      glds16(xrow[i] ? xrow[i] + cib : zero, xdst + i * 4096);
+      if (i < XR) glds16(xrow[i] ? xrow[i] + cib : zero, xdst + i * 4096);
     }
     if (++st_c == p.cpt) {
       st_c = 0;
@@ -123,25 +134,29 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     }
   };
 
-  // ---- accumulators: wave tile 64(n) x 64(m) = 4x4 fragments of 16x16
-  const int wm = wave & 1, wn = wave >> 1;
+  // ---- accumulators: wave tile 64(n) x 64(m) = 4x4 fragments of 16x16 (MT = 32: 32(n) x 32(m) = 2x2, waves along n)
+  const int wm = MT == 128 ? (wave & 1) : 0, wn = MT == 128 ? (wave >> 1) : wave;
+  const int noff = wn * (NI * 16), moff = wm * (MJ * 16);
   const float act_ns = act_neg_scale(p.act, p.slope);
   const bool act_sig = p.act == CFD_ACT_SIGMOID;
-  f32x4 acc[4][4];
+  f32x4 acc[NI][MJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
   // fragment byte offsets inside a tile for k-step 0 (k-step 1 is chunk + 4)
-  int aoff[4], boff[4];
+  int aoff[NI], boff[MJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra = wn * 64 + i * 16 + fr;
+  for (int i = 0; i < NI; ++i) {
+    const int ra = noff + i * 16 + fr;
     aoff[i] = ra * 128 + ((fq ^ (ra & 7)) << 4);
-    const int rb = wm * 64 + i * 16 + fr;
-    boff[i] = TILE_BYTES + rb * 128 + ((fq ^ (rb & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    const int rb = moff + j * 16 + fr;
+    boff[j] = TILE_BYTES + rb * 128 + ((fq ^ (rb & 7)) << 4);
   }
 
   if (kbeg < kend) stage(kbeg, 0);
@@ -150,38 +165,36 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt has landed for every wave; every wave is done reading the other buffer
     if (kt + 1 < kend) stage(kt + 1, buf ^ 1);
-    const char *base = lds + buf * STAGE_BYTES;
+    const char *base = lds + buf * STAGE;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       // chunk index for this k-step is (s*4 + fq); XOR with (row&7) only touches the low 3 bits, and
       // s*4 flips bit 2 -> equivalent to xor-ing the byte offset with 64
       if constexpr (sizeof(T) == 2) {
-        bf16x8 a[4], b[4];
+        bf16x8 a[NI], b[MJ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          a[i] = *(const bf16x8 *)(base + (aoff[i] ^ (s << 6)));
-          b[i] = *(const bf16x8 *)(base + (boff[i] ^ (s << 6)));
-        }
+        for (int i = 0; i < NI; ++i) a[i] = *(const bf16x8 *)(base + (aoff[i] ^ (s << 6)));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < MJ; ++j) b[j] = *(const bf16x8 *)(base + (boff[j] ^ (s << 6)));
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < MJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       } else {
         // f32: lane group fq supplies k = 16 s + 4 fq + e for e = 0..3 on BOTH operands (any
         // consistent k assignment sums to the same dot product), so one 16-B read feeds 4 MFMAs
-        f32x4 a[4], b[4];
+        f32x4 a[NI], b[MJ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          a[i] = *(const f32x4 *)(base + (aoff[i] ^ (s << 6)));
-          b[i] = *(const f32x4 *)(base + (boff[i] ^ (s << 6)));
-        }
+        for (int i = 0; i < NI; ++i) a[i] = *(const f32x4 *)(base + (aoff[i] ^ (s << 6)));
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) b[j] = *(const f32x4 *)(base + (boff[j] ^ (s << 6)));
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < MJ; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
       }
     }
@@ -189,19 +202,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 
   // ---- fused BatchNorm statistics (host guarantees: split_k == 1, Cout % 128 == 0, the 128 pixel rows of a
   // tile lie in ONE sample, none ragged): see igemm256.hip
-  if (p.stat_sum) {
+  if (MT == 128 && p.stat_sum) {
     __syncthreads();
     float *part = (float *)lds;   // [2][2 wm][128 n]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int nl = wn * 64 + i * 16 + fq * 4;
+    for (int i = 0; i < NI; ++i) {
+      const int nl = noff + i * 16 + fq * 4;
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) bv = *(const f32x4 *)(p.bias + n0 + nl);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < MJ; ++j) {
           const float v = acc[i][j][r] + bv[r];
           t1 += v;
           t2 = fmaf(v, v, t2);
@@ -226,8 +239,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 
   // ---- epilogue: lane holds channels n..n+3 (reg index) of pixel m
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wm * 64 + j * 16 + fr;
+  for (int j = 0; j < MJ; ++j) {
+    const int m = m0 + moff + j * 16 + fr;
     if (m >= p.M) continue;
     int b, qy, qx;
     split_pixel(p, m, b, qy, qx);
@@ -237,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     else
       opix = m;  // class grid == output grid
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = n0 + wn * 64 + i * 16 + fq * 4;
+    for (int i = 0; i < NI; ++i) {
+      const int n = n0 + noff + i * 16 + fq * 4;
       if (n >= p.Cout) continue;
       f32x4 v = acc[i][j];
       if (p.split_k > 1) {
@@ -314,6 +327,48 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float *__res
       *(bf16 *)(y + (pix * ldy + n) * 2) = (bf16)s;
     else
       *(float *)(y + (pix * ldy + n) * 4) = s;
+  }
+}
+
+// The same sum for SMALL outputs behind a deep K split (round 3: U b at batch 1 is 8 pixels x 1 024 channels behind 128
+// slabs): above, a thread walks all the slabs of its four channels -- 2 048 threads each with a chain of 128 loads.  Here a
+// block owns 64 consecutive channel quads (1 KiB of every slab), its four waves take every fourth slab, eight loads in
+// flight each, and fold through LDS.
+__global__ __launch_bounds__(256) void splitk_epilogue_small_kernel(const float *__restrict__ ws, const float *__restrict__ bias,
+                                                                   char *__restrict__ y, int64_t npix, int Cout, int ldy,
+                                                                   int split_k, int act, float slope, int out_bf16) {
+  __shared__ f32x4 part[4][64];
+  const int64_t total = npix * Cout;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t idx = ((int64_t)blockIdx.x * 64 + lane) * 4;
+  const bool live = idx < total;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    int k = wave;
+    for (; k + 28 < split_k; k += 32) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const f32x4 *)(ws + (int64_t)(k + 4 * u) * total + idx);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < split_k; k += 4) s += *(const f32x4 *)(ws + (int64_t)k * total + idx);
+  }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave != 0 || !live) return;
+  s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  const int64_t pix = idx / Cout;
+  const int n = (int)(idx - pix * Cout);
+  if (bias) s += *(const f32x4 *)(bias + n);
+  const float ns = act_neg_scale(act, slope);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) s[r] = act == CFD_ACT_SIGMOID ? apply_act(s[r], act, slope) : apply_act_linear(s[r], ns);
+  if (out_bf16) {
+    bf16x4 o = {(bf16)s[0], (bf16)s[1], (bf16)s[2], (bf16)s[3]};
+    *(bf16x4 *)(y + (pix * ldy + n) * 2) = o;
+  } else {
+    *(f32x4 *)(y + (pix * ldy + n) * 4) = s;
   }
 }
 
@@ -401,7 +456,9 @@ static bool use_igemm256(const IgemmParams &p, int dtype) {
   // and the launch fills at least half the chip; below that the 128x128 kernel's 2 blocks/CU hide more
   // (f32 with at most half a 256-row m tile of real rows -- DeltaP fc1 at B = 128 -- is MFMA-bound on the empty half:
   //  320 us on this kernel against 230 on the 128-row one)
-  if (dtype == CFD_F32 && p.M <= 128) return false;
+  //  and with two 256-row m tiles -- U e3 at batch 1, the reference's own batch size -- 82.6 us here against 57.8: the
+  //  split-K slabs of 256 x 256 tiles are four times the 128 x 128 kernel's per real row)
+  if (dtype == CFD_F32 && p.M <= 512) return false;
   const int blocks = cdiv(p.M, 256) * (p.Cout / igemm256_ntile(p)) * p.nclass;
   const int s = split_k_256(p);
   // (an f32 K tile is 8x the MFMA time of a bf16 one, so a much shorter slice already amortises the prologue)
@@ -414,12 +471,27 @@ static bool use_igemm256(const IgemmParams &p, int dtype) {
   return blocks * s >= 128 && (kt >= (dtype == CFD_BF16 ? 32 : 8) || (blocks >= 1024 && kt >= kt_many));
 }
 
+// the 32-row m tile: layers with at most 64 positions per class (two m tiles), which the 128-row tile would run mostly on
+// padding; cfd_set_tuning(CFD_TUNE_SKINNY, 0) turns it off (A/B)
+// (f32 only: the bf16 MFMA is 16 times faster, so the padding costs little there and the deeper split's slabs more --
+//  measured at batch 1, bf16: e5 21.8 -> 27.4 us, b 22.8 -> 28.5, d2 22.5 -> 26.3 on the 32-row tile)
+static bool use_skinny(const IgemmParams &p, int dtype) {
+  return dtype == CFD_F32 && p.M <= 64 && tuning(CFD_TUNE_SKINNY) != 0;
+}
+
 extern "C" int cfd_conv_suggest_split_k(const cfd_conv_desc *d) {
   cfd_conv_desc t = *d;
   t.split_k = 1;
   IgemmParams p;
   if (fill_params(&t, p) != CFD_OK) return 1;
   if (igemm_n64_eligible(p, d->dtype)) return 1;
+  if (use_skinny(p, d->dtype)) {
+    // four small workgroups per CU (1 024), at least four K tiles per slice: these layers stream their weights once
+    const int ktiles = p.ntaps * p.cpt, blocks = cdiv(p.M, 32) * p.ntiles * p.nclass;
+    int s = 1;
+    while (blocks * s * 2 <= 1024 && ktiles / (s * 2) >= 4) s *= 2;
+    return s;
+  }
   if (use_igemm256(p, d->dtype)) return split_k_256(p);
   const int ktiles = p.ntaps * p.cpt;
   int s = 1;
@@ -460,6 +532,12 @@ static int conv_forward_impl(const cfd_conv_desc *d, const void *x, const void *
   if (igemm_n64_eligible(p, d->dtype)) {
     rc = igemm_n64_launch(p, st);
     if (rc != CFD_OK) return rc;
+  } else if (use_skinny(p, d->dtype) && !p.stat_sum) {
+    p.mtiles = cdiv(p.M, 32);
+    p.nblocks = p.mtiles * p.ntiles * p.nclass * p.split_k;
+    const size_t sh = 2 * (TILE_BYTES + 32 * 128);
+    hipLaunchKernelGGL((igemm_kernel<float, 32>), dim3(p.nblocks), dim3(256), sh, st, p);
+    CFD_LAUNCH_CHECK();
   } else if (use_igemm256(p, d->dtype)) {
     rc = igemm256_launch(p, d->dtype, st);
     if (rc != CFD_OK) return rc;
@@ -478,7 +556,10 @@ static int conv_forward_impl(const cfd_conv_desc *d, const void *x, const void *
     const bool v4 = p.Cout % 4 == 0 && p.ldy % 4 == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0);
     const int64_t threads = v4 ? total / 4 : total;
     CFD_REQUIRE((threads + 255) / 256 < (1LL << 31), "split-K epilogue grid too large");
-    if (v4)
+    if (v4 && p.split_k >= 16 && threads <= 65536)
+      hipLaunchKernelGGL(splitk_epilogue_small_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(256), 0, st,
+                         (const float *)workspace, bias, (char *)y, npix, p.Cout, p.ldy, p.split_k, p.act, p.slope, p.out_bf16);
+    else if (v4)
       hipLaunchKernelGGL(splitk_epilogue_kernel<4>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
                          (const float *)workspace, bias, (char *)y, npix, p.Cout, p.ldy, p.split_k, p.act, p.slope, p.out_bf16);
     else

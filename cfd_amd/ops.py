@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, CONV_K3S1, CONV_K4S1, CONV_K4S2, CONVT_K4S2,
-                   DENSE, F32, TUNE_CLASS_ORDER, TUNE_IGEMM256, TUNE_STAGED_OUT, TUNE_IGEMM256_PD, TUNE_WGRAD256, TUNE_NTILE, TUNE_PATCH, TUNE_RESAMPLE_FUSED, TUNE_ONEPHASE, ConvDesc, check)
+                   DENSE, F32, TUNE_CLASS_ORDER, TUNE_IGEMM256, TUNE_STAGED_OUT, TUNE_IGEMM256_PD, TUNE_WGRAD256, TUNE_NTILE, TUNE_PATCH, TUNE_RESAMPLE_FUSED, TUNE_ONEPHASE, TUNE_SKINNY, ConvDesc, check)
 
 LEAKY_SLOPE = 0.2
 _DT = {torch.float32: F32, torch.bfloat16: BF16}

@@ -57,10 +57,12 @@ const char *cfd_last_error(void);
  *                         32 Ki points on average) | 0: the separate init / points / set-up / counting-sort launches
  *   CFD_TUNE_ONEPHASE     1: the 256-wide patch-staged kernel runs ONE cluster of 64 MFMAs per K tile (A1 fragments re-read
  *                         inside the cluster, LDS-DMA duty split by wave group) | 0 / -1: two clusters of 32 (igemm256h.hip)
+ *   CFD_TUNE_SKINNY       -1 / 1: layers with at most 64 output positions per class (batch 1: U e5, b, d1, d2) run on 32-row m tiles
+ *                         with a deeper K split | 0: on the 128-row tiles like every other layer
  */
 typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_WGRAD256 = 2, CFD_TUNE_CLASS_ORDER = 3,
                CFD_TUNE_STAGED_OUT = 4, CFD_TUNE_RESAMPLE_DENSITY = 5, CFD_TUNE_NTILE = 6, CFD_TUNE_PATCH = 7,
-               CFD_TUNE_RESAMPLE_FUSED = 8, CFD_TUNE_ONEPHASE = 9, CFD_TUNE_COUNT = 10 } cfd_tuning_key;
+               CFD_TUNE_RESAMPLE_FUSED = 8, CFD_TUNE_ONEPHASE = 9, CFD_TUNE_SKINNY = 10, CFD_TUNE_COUNT = 11 } cfd_tuning_key;
 int cfd_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------

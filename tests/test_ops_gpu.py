@@ -77,6 +77,36 @@ def test_conv_forward(kind, B, H, W, cin, cout, dtype):
     assert relerr(y.cpu(), ref) <= 1e-4
 
 
+@pytest.mark.parametrize("skinny", [1, 0])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind,B,H,W,cin,cout", [
+    ("k4s2", 1, 2, 16, 1024, 1024),    # U b at batch 1: 8 output pixels, 256 / 512 K tiles
+    ("k4s2", 1, 4, 32, 512, 320),      # e5-like: 32 pixels = one 32-row tile; a ragged n tile
+    ("k4s2", 2, 4, 32, 256, 128),      # 64 pixels: two m tiles
+    ("k4s2", 5, 2, 8, 128, 128),       # 20 pixels: a ragged m tile
+    ("convT", 1, 1, 8, 1024, 512),     # d1: 8 positions per class
+    ("convT", 1, 2, 16, 256, 256),     # d2-like: 32 per class
+    ("k3s1", 1, 4, 12, 128, 128),      # 48 pixels, 3 x 3 taps
+    ("dense", 1, 1, 1, 8192, 256),     # fc1-like at batch 1
+])
+def test_conv_forward_few_output_positions(kind, B, H, W, cin, cout, dtype, skinny):
+    """f32 layers with at most 64 output positions per class run on 32-row m tiles (CFD_TUNE_SKINNY, default on): same result
+    as the oracle with the switch on and off, and the library asks for a deeper K split with it on (whose small outputs take
+    the slab-parallel split-K epilogue in both dtypes)"""
+    from cfd_amd import ops
+    ops.set_tuning(ops.TUNE_SKINNY, skinny)
+    try:
+        test_conv_forward(kind, B, H, W, cin, cout, dtype)
+        if kind == "k4s2" and cin == 1024 and dtype == torch.float32:     # (the 32-row tile serves f32 only)
+            d = ops.ConvDesc(kind=ops.CONV_K4S2, dtype=ops._DT[dtype], out_dtype=ops._DT[dtype], B=B, Hi=H, Wi=W, Cin=cin,
+                             Cout=cout, ldx=cin, ldy=cout, act=0, leaky_slope=0.0, split_k=1)
+            from cfd_amd import _lib
+            s = _lib.load().cfd_conv_suggest_split_k(d)
+            assert (s >= 32) if skinny else (s <= 64)
+    finally:
+        ops.set_tuning(ops.TUNE_SKINNY, -1)
+
+
 @pytest.mark.parametrize("dtype,pd", [(torch.bfloat16, 5), (torch.bfloat16, 6), (torch.bfloat16, 26), (torch.float32, 6)])
 @pytest.mark.parametrize("kind,B,H,W,cin,cout,split_k", [
     ("k4s2", 2, 16, 64, 64, 256, 1),      # two full 256-row tiles, one tap-major K sweep
