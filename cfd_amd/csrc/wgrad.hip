@@ -193,6 +193,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   }
 
   // ---- store / accumulate: lane holds dW[co = .. + fq*4 + r][ci = .. + fr]
+  // Whole tiles that are STORED (no atomics, one tap per tile) leave through LDS as full rows of CT channels (256 B f32 /
+  // 512 B bf16-mode): straight from the fragments a store instruction covers four 64-byte pieces, and the weight-gradient
+  // launches whose output is most of their traffic (batch 1: U b, 67 MB for 8 pixels; DeltaP fc1, 268 MB) wrote at 0.7-2 TB/s.
+  if (!p.pair && (p.slab || p.split_m == 1) && co0 + CT <= p.Cout && ci0 + CT <= p.Cin && (p.Cin & 3) == 0) {
+    constexpr int PITCH = CT + 4;
+    float *tile = (float *)lds;
+    __syncthreads();   // every wave is done with the operand stages
+#pragma unroll
+    for (int i = 0; i < FR; ++i)
+#pragma unroll
+      for (int j = 0; j < FR; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          tile[(wco + i * 16 + fq * 4 + r) * PITCH + wci + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    const int wtap = p.flip ? (p.ntaps - 1 - tap) : tap;
+    float *dst = p.slab ? p.slab + (int64_t)sm * p.dw_elems : p.dw;
+    constexpr int CPR = CT / 4;                       // 16-B chunks per row
+    for (int e = tid; e < CT * CPR; e += 256) {
+      const int row = e / CPR, c4 = (e - row * CPR) * 4;
+      const f32x4 v = *(const f32x4 *)(tile + row * PITCH + c4);
+      *(f32x4 *)(dst + ((int64_t)(co0 + row) * p.ntaps + wtap) * p.Cin + ci0 + c4) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < FR; ++i)
 #pragma unroll
@@ -279,7 +304,9 @@ static int conv_wgrad_impl(const cfd_conv_desc *d, const void *x, const void *dy
   p.dw_elems = (int64_t)d->Cout * p.ntaps * d->Cin;
   p.slab = (p.split_m > 1 && workspace && p.dw_elems % 4 == 0) ? (float *)workspace : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  const size_t shmem = 2 * W_STAGE_BYTES;
+  // (the staged epilogue's tile: CT x (CT + 4) floats -- 66 KiB in bf16 mode, a little over the two operand stages)
+  const size_t ctile = d->dtype == CFD_BF16 ? 128 : 64;
+  const size_t shmem = std::max<size_t>(2 * W_STAGE_BYTES, ctile * (ctile + 4) * 4);
   if (d->dtype == CFD_BF16) {
     if (int e_ = set_max_lds((const void *)wgrad_kernel<bf16>, (int)shmem)) return e_;
     hipLaunchKernelGGL(wgrad_kernel<bf16>, dim3(p.nblocks), dim3(256), shmem, st, p);
