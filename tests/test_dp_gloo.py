@@ -5,6 +5,7 @@ need a GPU; here the flat gradient buffers are plain CPU tensors."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -161,8 +162,10 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_dp_allreduce_and_sharding_world2():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_dp_allreduce_and_sharding(world):
+    """(world 4 as well: the sharded ranges' chunking and the case split must hold beyond two ranks -- the first hardware
+    run of 4 and 8 ranks is the driver's)"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -174,8 +177,10 @@ def test_dp_allreduce_and_sharding_world2():
         p.join(60)
     assert all(r[1] for r in res)
     # contiguous, disjoint, covering
-    assert res[0][2] == 0 and res[0][3] == res[1][2] and res[1][3] == 10001
-    assert abs((res[0][3] - res[0][2]) - (res[1][3] - res[1][2])) <= 1
+    assert res[0][2] == 0 and res[-1][3] == 10001
+    assert all(a[3] == b[2] for a, b in zip(res[:-1], res[1:]))
+    sizes = [r[3] - r[2] for r in res]
+    assert max(sizes) - min(sizes) <= 1
 
 
 def test_case_range_properties():
