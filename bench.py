@@ -272,6 +272,37 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+_mfma_probe_memo = {}
+
+
+def mfma_register_only():
+    """What the matrix cores sustain in THIS process on THIS chip with nothing else in the loop (cfd_mfma_probe: bf16
+    16x16x32 MFMAs on register operands, 8 waves per CU), on random operands and on zeros -- measured live, HIP events,
+    median of 5 launches of ~2 ms after 3 warm-up launches.  Context for the bf16 rooflines: `peak` stays the 2.5 PFLOP/s
+    of the guide; the clock the chip holds under MFMA load depends on how many operand bits toggle."""
+    if _mfma_probe_memo:
+        return _mfma_probe_memo
+    from cfd_amd import ops
+    out = torch.empty(256 * 512, dtype=torch.float32, device="cuda")
+    res = {}
+    for name in ("random", "zero"):
+        src = (torch.randn(65536 * 8, device="cuda") if name == "random" else torch.zeros(65536 * 8, device="cuda")).to(torch.bfloat16)
+        for _ in range(3):
+            flop = ops.mfma_probe(src, out, 4096)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in ev:
+            a.record()
+            ops.mfma_probe(src, out, 4096)
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)[2]
+        res[name + "_operands"] = round(flop / (ms * 1e-3) / 1e12, 1)
+    res.update(unit="TFLOP/s", kernel="cfd_mfma_probe: v_mfma_f32_16x16x32_bf16 on register operands, 8 waves per CU, no LDS / memory in the loop",
+               note="measured in this run; the ceiling of any schedule on operands that toggle, beside the guide's 2500 (peak)")
+    _mfma_probe_memo.update(res)
+    return _mfma_probe_memo
+
+
 def profile_source(path, summary):
     """where a PMC-derived figure in the line comes from: NOT this run -- a committed profile of the same command"""
     return {"file": os.path.relpath(path, ROOT), "git_head": summary.get("git_head"), "csrc_sha16": summary.get("csrc_sha16"),
@@ -416,6 +447,8 @@ def run_model_workload(name, B, steps, warmup, rank, world, cpu_base):
                     frac=round(achieved / peak, 4), traffic=traffic, mfma_busy_frac_pmc=busy, traffic_source=src,
                     launches_per_step=sm["launches"] // n_roof,
                     avg_launch_us=round(sm["total_ms"] * 1e3 / sm["launches"], 2))
+        if wl["dtype"] == "bf16":
+            roof["mfma_register_only"] = mfma_register_only()
     out = {"value": round(world * B * steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "dtype": wl["dtype"],
            "config": {"workload": name, "nets": wl["nets"], "per_gpu_batch": B, "global_batch": B * world,

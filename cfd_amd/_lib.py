@@ -82,6 +82,7 @@ SIGNATURES = {
     "cfd_dropout_apply": (_i, [_vp, _vp, _vp, _i64, _f, C.c_uint64, _i64, _i, _vp]),
     "cfd_bce_logits": (_i, [_vp, _vp, _f, _i64, _vp, _vp, _f, _vp]),
     "cfd_field_loss": (_i, [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp, _i, _vp]),
+    "cfd_mfma_probe": (_i, [_vp, _vp, _i, _vp]),
     "cfd_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _f, _vp]),
     "cfd_bn_update_moving": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "cfd_bn_update_moving_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),

@@ -820,6 +820,15 @@ def field_loss(y, target, kind, loss, dout=None, weight=1.0, delta=1.0, dy_extra
                                      _ptr(dy_extra), _ptr(dout), int(sigmoid_grad), _stream()), "cfd_field_loss")
 
 
+def mfma_probe(operands: torch.Tensor, out: torch.Tensor, iters: int) -> float:
+    """one launch of the register-only bf16 MFMA loop (cfd_mfma_probe); returns the FLOP it performs"""
+    _need(operands.dtype == torch.bfloat16 and operands.numel() >= 65536 * 8 and operands.is_contiguous(),
+          "mfma_probe: operands must be >= 524288 contiguous bf16 values")
+    _numel(out, 256 * 512, "mfma_probe out", torch.float32)
+    check(_lib.load().cfd_mfma_probe(_ptr(operands), _ptr(out), int(iters), _stream()), "cfd_mfma_probe")
+    return 2.0 * 16 * 16 * 32 * 32.0 * iters * 8 * 256
+
+
 def adam_step(w, g, m, v, w_compute, alpha, beta1, beta2=0.999, eps=1e-7, grad_scale=1.0):
     n = w.numel()
     for t, what in ((w, "w"), (g, "g"), (m, "m"), (v, "v")):

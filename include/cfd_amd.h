@@ -65,6 +65,14 @@ typedef enum { CFD_TUNE_IGEMM256 = 0, CFD_TUNE_IGEMM256_PD = 1, CFD_TUNE_WGRAD25
                CFD_TUNE_RESAMPLE_FUSED = 8, CFD_TUNE_ONEPHASE = 9, CFD_TUNE_SKINNY = 10, CFD_TUNE_COUNT = 11 } cfd_tuning_key;
 int cfd_set_tuning(int key, int value);
 
+/* Measurement aid, no counterpart in the reference: `iters` rounds of 32 independent v_mfma_f32_16x16x32_bf16 per wave on
+ * REGISTER operands (8 waves on each of 256 workgroups; no LDS, no memory traffic inside the loop) -- what the matrix
+ * cores sustain on the operand values given, against which bench.py sets the conv kernels' TFLOP/s beside the 2.5 PFLOP/s
+ * peak (the chip's clock under MFMA load depends on how many operand bits toggle: DESIGN.md section 5 (k2)).
+ * operands: 65 536 x 16 bytes (bf16 values, device memory), out: 256 x 512 floats (device memory, sink).
+ * Work: 2 * 16*16*32 * 32 * iters * 8 * 256 FLOP per call. */
+int cfd_mfma_probe(const void *operands, float *out, int iters, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Convolutions as implicit GEMM on MFMA.
  * Replaces Conv2D / Conv2DTranspose / Dense of

@@ -901,3 +901,19 @@ def test_bn_stats_then_apply(B, H, W, C, dtype):
     assert relerr(stats[0].cpu() / (H * W), st["l"][0]) <= 2e-5
     assert relerr(mean.cpu(), st["l"][0]) <= 2e-5 and relerr(var.cpu(), st["l"][1]) <= 2e-4
     assert relerr(y.float().cpu(), O.leaky(ref)) <= TOL[dtype]
+
+
+def test_mfma_probe_runs_and_counts_its_work():
+    """cfd_mfma_probe (bench.py's register-only MFMA rate): zero operands leave zeros, ones leave iters * 32 tiles' worth of
+    sums, and the FLOP count it reports is that of its grid"""
+    from cfd_amd import ops
+    out = torch.full((256 * 512,), 7.0, device="cuda")
+    flop = ops.mfma_probe(torch.zeros(65536 * 8, dtype=torch.bfloat16, device="cuda"), out, 3)
+    torch.cuda.synchronize()
+    assert flop == 2 * 16 * 16 * 32 * 32 * 3 * 8 * 256 and float(out.abs().max()) == 0.0
+    ops.mfma_probe(torch.ones(65536 * 8, dtype=torch.bfloat16, device="cuda"), out, 3)
+    torch.cuda.synchronize()
+    # every accumulator element = 3 rounds x K = 32 ones; a lane holds 4 elements of each of its 32 tiles
+    assert torch.equal(out, torch.full_like(out, 3 * 32 * 4 * 32.0))
+    with pytest.raises(Exception):
+        ops.mfma_probe(torch.ones(64, dtype=torch.bfloat16, device="cuda"), out, 3)
