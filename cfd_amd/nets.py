@@ -516,9 +516,10 @@ class CnnRegressor(_Net):
         return y
 
     def backward(self, dy: torch.Tensor, x: torch.Tensor, drop_mask: Optional[torch.Tensor] = None, seed: int = 0,
-                 sample0: int = 0) -> None:
+                 sample0: int = 0, side_wgrad: bool = False) -> None:
         """Backward of the training forward that JUST ran; dy = dL/dy fp32 (B,1)."""
         self.check_image(x)
+        self.wgrad_begin(side_wgrad)
         P, B = self.params, x.shape[0]
         if tuple(dy.shape) != (B, 1):
             raise ValueError(f"dy must be ({B}, 1), got {tuple(dy.shape)}")
@@ -534,7 +535,7 @@ class CnnRegressor(_Net):
         ops.tap_dx(dy, P.c("fc3.kernel"), df2.view(B, 1, 1, 128), 1)
         dpre2 = self.buf(pl, "dpre_fc2", (B, 128))
         ops.act_bwd(f2.view(B, 1, 1, 128), df2.view(B, 1, 1, 128), ACT_RELU, dpre2.view(B, 1, 1, 128), dbias=P.g("fc2.bias"))
-        ops.conv_wgrad(f1d, dpre2, DENSE, 128, P.g("fc2.kernel"))
+        self.wgrad(lambda: ops.conv_wgrad(f1d, dpre2, DENSE, 128, P.g("fc2.kernel")))
         df1d = self.buf(pl, "dfc1d", (B, 256))
         ops.conv_forward(dpre2, P.t("fc2.kernel"), None, DENSE, 256, out=df1d)
         df1 = self.buf(pl, "dfc1", (B, 256))
@@ -543,7 +544,7 @@ class CnnRegressor(_Net):
         ops.act_bwd(f1.view(B, 1, 1, 256), df1.view(B, 1, 1, 256), ACT_RELU, dpre1.view(B, 1, 1, 256), dbias=P.g("fc1.bias"))
         g7 = pl["g7"]
         flat = g7.view(B, -1)
-        ops.conv_wgrad(flat, dpre1, DENSE, 256, P.g("fc1.kernel"))
+        self.wgrad(lambda: ops.conv_wgrad(flat, dpre1, DENSE, 256, P.g("fc1.kernel")))
         dg7 = self.buf(pl, "dg7", g7.shape)
         ops.conv_forward(dpre1, P.t("fc1.kernel"), None, DENSE, flat.shape[1], out=dg7.view(B, -1))
         # g6 -> pool: pool backward fused with g6's ReLU backward
@@ -552,19 +553,20 @@ class CnnRegressor(_Net):
         # (bias gradients ride with the pass that writes the pre-activation gradient: a separate column-sum pass re-read
         #  536 MB per B = 64 step at 1.9 TB/s, 6.9 % of the step)
         ops.maxpool2_act_bwd(g6, dg7, dpre6, ACT_RELU, dbias=P.g("g6.bias"))
-        ops.conv_wgrad(g5, dpre6, CONV_K3S1, 512, P.g("g6.kernel"))
+        self.wgrad(lambda: ops.conv_wgrad(g5, dpre6, CONV_K3S1, 512, P.g("g6.kernel")))
         dg5 = self.buf(pl, "dg5", g5.shape)
         ops.conv_forward(dpre6, P.t("g6.kernel"), None, CONV_K3S1, 256, out=dg5)
         dpre4 = self.buf(pl, "dpre_g4", g4.shape)
         ops.maxpool2_act_bwd(g4, dg5, dpre4, ACT_RELU, dbias=P.g("g4.bias"))
-        ops.conv_wgrad(g3, dpre4, CONV_K3S1, 256, P.g("g4.kernel"))
+        self.wgrad(lambda: ops.conv_wgrad(g3, dpre4, CONV_K3S1, 256, P.g("g4.kernel")))
         dg3 = self.buf(pl, "dg3", g3.shape)
         ops.conv_forward(dpre4, P.t("g4.kernel"), None, CONV_K3S1, 128, out=dg3)
         dpre3 = self.buf(pl, "dpre_g3", g3.shape)
         ops.act_bwd(g3, dg3, ACT_RELU, dpre3, dbias=P.g("g3.bias"))
-        ops.conv_wgrad(g2, dpre3, CONV_K3S1, 128, P.g("g3.kernel"))
+        self.wgrad(lambda: ops.conv_wgrad(g2, dpre3, CONV_K3S1, 128, P.g("g3.kernel")))
         dg2 = self.buf(pl, "dg2", g2.shape)
         ops.conv_forward(dpre3, P.t("g3.kernel"), None, CONV_K3S1, 64, out=dg2)
         dpre1c = self.buf(pl, "dpre_g1", g1.shape)
         ops.maxpool2_act_bwd(g1, dg2, dpre1c, ACT_LEAKY)
         ops.conv_first_wgrad(x, None, dpre1c, P.g("g1.kernel"), P.g("g1.bias"), 3, 1)
+        self.wgrad_join()

@@ -551,7 +551,7 @@ class CnnTrainer:
         pred = c.forward(x, training=True, drop_mask=drop_mask, seed=seed, sample0=sample0)
         dy = c.buf(c.plan(B), "dy", pred.shape, torch.float32)
         ops.field_loss(pred, y, ops.HUBER, self.loss, dy, weight=self.weight, delta=self.delta)
-        c.backward(dy, x, drop_mask=drop_mask, seed=seed, sample0=sample0)
+        c.backward(dy, x, drop_mask=drop_mask, seed=seed, sample0=sample0, side_wgrad=_side_wgrad(self.dp))
         self.dp.reduce_range_async(P, 0, P.n_trainable)
         self.dp.apply(P, self.opt)
         P.refresh_transposed(side_stream=True)
