@@ -100,6 +100,7 @@ SIGNATURES = {
     "cfd_resample_nearest": (_i, [_vp, _vp, _i, _i64, _vp, _i, _vp, _i, _vp, _i, _d, _d, _d, _vp, _vp, _vp]),
     "cfd_resample_nearest_counted": (_i, [_vp, _vp, _i, _i64, _vp, _i, _vp, _i, _vp, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
     "cfd_csv_format_rows": (_i64, [_vp, _i64, _i, _vp, _i64]),
+    "cfd_csv_parse_columns": (_i64, [C.c_char_p, _i64, C.c_char_p, C.c_char_p, _vp, _vp, _i64]),
 }
 
 _lib = None

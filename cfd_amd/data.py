@@ -27,6 +27,15 @@ CACHE_VERSION = "v2"      # v2: values parsed as float() does (round-trip exact)
 INGEST_THREADS = int(os.environ.get("CFD_AMD_INGEST_THREADS", "0")) or min(16, os.cpu_count() or 1)
 
 
+import threading
+
+_PANDAS_LOCK = threading.Lock()
+
+
+def _native_parse() -> bool:
+    return os.environ.get("CFD_AMD_NATIVE_CSV", "1") != "0"
+
+
 def signed_distance(phi: np.ndarray, dx: float) -> np.ndarray:
     """skfmm.distance(phi, dx) for a +-1 mask (utils.py:100-103), on the GPU."""
     from . import ops
@@ -59,13 +68,25 @@ def read_case(path: str, height: int = 64, width: int = 512, cache_dir: Optional
             a = np.load(entry, allow_pickle=False)
             if a.shape == (2, height, width) and a.dtype == np.float64:
                 return a[0], a[1]
-    import pandas as pd
     # the reference parses every field with Python's float() (utils.py:81-83: csv.DictReader + float(row[...])), which
-    # is correctly rounded; pandas' DEFAULT parser is not (last-bit differences in ~15 % of values), its
-    # "round_trip" parser is (it calls the same strtod as float()): CPU-tested against a csv.DictReader restatement
-    df = pd.read_csv(io.BytesIO(raw), float_precision="round_trip")
-    p = np.asarray(df["p_convert"].to_numpy(), dtype=np.float64).reshape(height, width)
-    u = np.asarray(df["Umean_center"].to_numpy(), dtype=np.float64).reshape(height, width)
+    # is correctly rounded; pandas' DEFAULT parser is not (last-bit differences in ~15 % of values).  The library's
+    # host-side reader (cfd_csv_parse_columns: strtod, correctly rounded, no GIL) reads plain numeric files; anything it
+    # does not vouch for goes to pandas' "round_trip" parser (the same strtod, under the GIL).  Both CPU-tested against a
+    # csv.DictReader + float() restatement.
+    p = u = None
+    if _native_parse():
+        from . import _lib
+        pa, ua = np.empty(height * width, dtype=np.float64), np.empty(height * width, dtype=np.float64)
+        n = _lib.load().cfd_csv_parse_columns(raw, len(raw), b"p_convert", b"Umean_center", pa.ctypes.data, ua.ctypes.data,
+                                              height * width)
+        if n == height * width:
+            p, u = pa.reshape(height, width), ua.reshape(height, width)
+    if p is None:
+        import pandas as pd
+        with _PANDAS_LOCK:          # (its round-trip parser holds the GIL: threads only thrash over it)
+            df = pd.read_csv(io.BytesIO(raw), float_precision="round_trip")
+        p = np.asarray(df["p_convert"].to_numpy(), dtype=np.float64).reshape(height, width)
+        u = np.asarray(df["Umean_center"].to_numpy(), dtype=np.float64).reshape(height, width)
     if entry:
         os.makedirs(cache_dir, exist_ok=True)
         tmp = f"{entry}.{os.getpid()}.tmp"

@@ -398,6 +398,16 @@ int cfd_resample_nearest_noalloc(const double *pts, const int64_t *case_offsets,
  *   out    HOST char buffer of `cap` >= n_rows * n_cols * 26 bytes
  * Returns the number of bytes written (>= 0), or a negative cfd_status. */
 int64_t cfd_csv_format_rows(const double *rows, int64_t n_rows, int n_cols, char *out, int64_t cap);
+/* HOST-side reader for the ingest: two named columns of a numeric CSV as fp64, each field parsed as Python's float() parses
+ * it -- /root/reference utils.py:72-83 (`csv.DictReader`, `float(row['p_convert'])`, `float(row['Umean_center'])`); both are
+ * correctly rounded, so the doubles are the same bit for bit.  Runs without Python's GIL (pandas' round-trip parser holds it:
+ * 0.8 s a case from 16 threads).
+ *   text/len  the file's bytes (HOST);  name_a, name_b  column names (NUL-terminated);  out_a, out_b  HOST fp64 [cap]
+ * Returns the number of data rows (>= 0); -2 when the text holds anything this plain parser does not vouch for (quotes, '_'
+ * separators, hex floats, empty / malformed fields, ragged rows, a missing column, more than `cap` rows): the caller then
+ * uses a general CSV reader; another negative cfd_status on bad arguments. */
+int64_t cfd_csv_parse_columns(const char *text, int64_t len, const char *name_a, const char *name_b, double *out_a,
+                              double *out_b, int64_t cap);
 
 /* ------------------------------------------------------------------------------------
  * Dataset build: what utils.load_data computes per case after parsing the CSV (utils.py:89-103).

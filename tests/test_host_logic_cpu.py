@@ -206,10 +206,13 @@ def _dictreader_column(path, col):
         return np.asarray([float(row[col]) for row in csv.DictReader(fh)], dtype=np.float64)
 
 
-def test_read_case_parses_like_python_float(tmp_path):
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_read_case_parses_like_python_float(tmp_path, native, monkeypatch):
     """A8: utils.py:82-83 parses with float(); pandas' default parser differs from it in the last bit for ~15 % of
-    17-digit values, so the ingest uses the round-trip parser.  200 000 values, bit for bit."""
+    17-digit values, so the ingest uses the library's strtod reader (native = 1) or pandas' round-trip parser (0, and
+    the fallback).  200 000 values, bit for bit."""
     from cfd_amd import data as D
+    monkeypatch.setenv("CFD_AMD_NATIVE_CSV", native)
     r = np.random.default_rng(11)
     h, w = 200, 500
     a = np.concatenate([r.normal(size=(h * w // 2, 2)) * 10.0 ** r.integers(-8, 8, size=(h * w // 2, 1)),
@@ -225,6 +228,38 @@ def test_read_case_parses_like_python_float(tmp_path):
     assert np.array_equal(u_got.ravel().view(np.uint64), u_ref.view(np.uint64))
     default = pd.read_csv(path)["p_convert"].to_numpy()
     assert (default.view(np.uint64) != p_ref.view(np.uint64)).any(), "the default parser no longer differs: test is vacuous"
+
+
+def test_native_csv_reader_spellings_and_fallbacks(tmp_path):
+    """cfd_csv_parse_columns against csv.DictReader + float() on the spellings float() accepts, and its refusals (-2:
+    the ingest then takes pandas' round-trip parser): quotes, '_' separators, hex, empty fields, ragged rows, a missing
+    column, more rows than expected."""
+    import ctypes as C
+    from cfd_amd import _lib, data as D
+    lib = _lib.load()
+    vals = ["nan", "inf", "-inf", "Infinity", "-NaN", "1e-320", "4.9e-324", "1.7976931348623157e308", "+1.5", " 2.5 ", "1E5",
+            ".5", "5.", "-0.0", "0.1", "123456789012345678901234567890", "2.2250738585072011e-308", "9007199254740993",
+            "0.30000000000000004", "1e23", "8.41e21", "2.4703282292062327e-324", "1e400", "-1e-400"]
+    text = "a,p_convert,b,Umean_center\r\n" + "".join(f"0,{v},7,{w}\r\n" for v, w in zip(vals, reversed(vals))) + "\n"
+    path = tmp_path / "s.csv"
+    path.write_bytes(text.encode())
+    want_p, want_u = _dictreader_column(path, "p_convert"), _dictreader_column(path, "Umean_center")
+    raw = path.read_bytes()
+    pa, ua = np.full(len(vals), 7.0), np.full(len(vals), 7.0)
+    n = lib.cfd_csv_parse_columns(raw, len(raw), b"p_convert", b"Umean_center", pa.ctypes.data, ua.ctypes.data, len(vals))
+    assert n == len(vals)
+    assert np.array_equal(pa.view(np.uint64), want_p.view(np.uint64)) and np.array_equal(ua.view(np.uint64), want_u.view(np.uint64))
+    head = "p_convert,Umean_center\n"
+    for bad in (head + '"1.0",2.0\n', head + "1_0,2.0\n", head + "0x1p3,2.0\n", head + ",2.0\n", head + "1.0\n",
+                head + "1.0,2.0,3.0\n", "x,Umean_center\n1.0,2.0\n", head + "1.0,2.0\n3.0,4.0\n", head + "1.0.0,2\n",
+                head + "1e,2\n", "no newline"):
+        b = bad.encode()
+        assert lib.cfd_csv_parse_columns(b, len(b), b"p_convert", b"Umean_center", pa.ctypes.data, ua.ctypes.data, 1) == -2, bad
+    # the ingest falls back to pandas for a file the native reader refuses (quoted numbers), with the same doubles
+    q = tmp_path / "q.csv"
+    q.write_text("p_convert,Umean_center\n" + "".join(f'"{0.1 * i!r}",{0.3 * i!r}\n' for i in range(6)))
+    p, u = D.read_case(str(q), 2, 3)
+    assert np.array_equal(p.ravel(), np.array([0.1 * i for i in range(6)])) and np.array_equal(u.ravel(), np.array([0.3 * i for i in range(6)]))
 
 
 def test_forward_chunked_host_logic(monkeypatch):
